@@ -1,0 +1,113 @@
+/* jurassic_hip.h -- C-ABI of the MI355X forward-model library (libjurassic_hip.so).
+ *
+ * Two groups of entry points, all plain C, no C++/torch types:
+ *
+ * (1) DROP-IN symbols, exactly what the reference's host code binds:
+ *       formod()         reference src/jurassic.h:515-518, body CPUdrivers.c:179-194
+ *       formod_GPU()     reference src/GPUdrivers.cu:253-262 (declared CPUdrivers.c:153-155);
+ *                        this is the object the reference links instead of GPUdrivers.o
+ *       formod_pencil()  reference src/jurassic.h:526-530 (prototype only upstream)
+ *     Same argument meaning, ownership and error behaviour as upstream: void
+ *     return, a failure prints a message and terminates the process; tables are
+ *     loaded from ${TBLBASE}_${nu}_${gas}.tab / .filt on first use and cached for
+ *     the life of the process (jr_common.h:60-78).
+ *
+ * (2) ADDITIVE batched API (jur_*), for more than NR rays per call and for
+ *     callers that already hold their arrays in device memory.  Returns 0 on
+ *     success, a negative JUR_E* code otherwise; jur_last_error() has the text.
+ */
+#ifndef JURASSIC_HIP_H
+#define JURASSIC_HIP_H
+
+#include "jurassic_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- (1) drop-in ---------------------------------------------------------- */
+void formod(ctl_t const *ctl, atm_t *atm, obs_t *obs);
+void formod_GPU(ctl_t const *ctl, atm_t *atm, obs_t *obs);
+void formod_pencil(ctl_t const *ctl, atm_t *atm, obs_t *obs, int const ir);
+
+/* ---- (2) additive --------------------------------------------------------- */
+enum {
+  JUR_OK = 0,
+  JUR_EINVAL = -1,    /* bad argument / unsupported control setting          */
+  JUR_EIO = -2,       /* table or filter file problem                        */
+  JUR_ENOMEM = -3,
+  JUR_EHIP = -4,      /* HIP runtime error                                   */
+  JUR_ENLOS = -5,     /* a line of sight needs >= NLOS points (jr_common.h:693) */
+  JUR_ENODEV = -6     /* no usable GPU                                       */
+};
+
+char const *jur_last_error(void);
+
+/* sizeof(ctl_t), sizeof(atm_t), sizeof(obs_t), ND, NG the library was built with */
+void jur_abi_sizes(size_t out[5]);
+
+/* Host-side emissivity tables under construction. */
+typedef struct jur_tables jur_tables_t;
+jur_tables_t *jur_tables_new(int ng, int nd);
+void jur_tables_free(jur_tables_t *tb);
+/* Feed the rows (p [hPa], T [K], u [molec/cm^2], eps) of one (gas, channel)
+ * table in file order; row acceptance follows reference jurassic.c:346-395. */
+int jur_tables_feed_rows(jur_tables_t *tb, int ig, int id, long nrows,
+                         double const *p, double const *t, double const *u, double const *eps);
+/* Parse every ${tblbase}_${nu:%.4f}_${emitter}.tab named by ctl; missing files
+ * leave that pair without table (transparent), as upstream.  Returns the number
+ * of files found or a negative error. */
+int jur_tables_read_ascii(jur_tables_t *tb, ctl_t const *ctl);
+/* Filter function of one channel -> source-function table (jurassic.c:612-667). */
+int jur_tables_set_filter(jur_tables_t *tb, int id, int n, double const *nu, double const *f);
+int jur_tables_read_filters(jur_tables_t *tb, ctl_t const *ctl);
+/* number of stored (u,eps) entries, for reporting */
+long jur_tables_entries(jur_tables_t const *tb);
+
+/* A model = control settings + tables + per-channel continuum constants,
+ * resident on one GPU (`device` = HIP device ordinal). */
+typedef struct jur_model jur_model_t;
+int  jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb, int device);
+/* convenience: tables + filters from the files ctl names */
+int  jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device);
+void jur_model_destroy(jur_model_t *m);
+
+/* Upload the atmosphere (only atm->np points and ctl->ng gases travel).
+ * Applies the hydrostatic adjustment first if ctl->hydz >= 0 -- on a private
+ * copy; the caller's atm is not modified (GPU-path behaviour upstream,
+ * GPUdrivers.cu:243). */
+int  jur_model_set_atm(jur_model_t *m, atm_t const *atm);
+
+/* Forward model for nr rays, host arrays.  geom[7] = {time, obsz, obslon,
+ * obslat, vpz, vplon, vplat}, each [nr].  rad/tau are [nr][nd] (nd = ctl->nd,
+ * channel fastest); rad is read first: channels that hold a non-finite value
+ * on input come back NaN (jr_common.h:193-210).  tp[3] = {tpz, tplon, tplat},
+ * each [nr].  np_out (optional) receives the number of LOS points per ray. */
+int  jur_formod_host(jur_model_t *m, long nr, double const *const geom[7],
+                     double *rad, double *tau, double *const tp[3], int *np_out);
+
+/* Same, all pointers in device memory of the model's GPU; work is enqueued on
+ * `stream` (a hipStream_t, may be NULL) and the call returns without waiting.
+ * d_geom is [7][nr], d_tp is [3][nr], d_np (optional) [nr].
+ * d_status (optional, int[1]) is set non-zero on device if a ray overflowed NLOS. */
+int  jur_formod_device(jur_model_t *m, long nr, double const *d_geom,
+                       double *d_rad, double *d_tau, double *d_tp, int *d_np,
+                       int *d_status, void *stream);
+
+/* Bytes of device workspace the model holds for `nr` rays per call, and the
+ * chunk size (rays per kernel launch) it uses. */
+long jur_model_workspace_bytes(jur_model_t const *m);
+int  jur_model_chunk_rays(jur_model_t const *m);
+/* Tuning knobs (before the first formod call): rays per chunk. */
+int  jur_model_set_chunk_rays(jur_model_t *m, int rays);
+
+/* Duration in ms of the most recent launch of each kernel on this model,
+ * measured with HIP events on the launch stream when profiling is enabled
+ * (jur_model_enable_timing(m, 1)); [0]=trace [1]=integrate. */
+int  jur_model_enable_timing(jur_model_t *m, int on);
+int  jur_model_last_kernel_ms(jur_model_t *m, double out_ms[2], long out_launches[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

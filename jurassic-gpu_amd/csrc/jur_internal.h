@@ -1,0 +1,125 @@
+/* jur_internal.h -- structures shared by the C host code and the HIP kernels.
+ * Plain C so that gcc (host) and hipcc (device) agree on the layout. */
+#ifndef JUR_INTERNAL_H
+#define JUR_INTERNAL_H
+
+#include <stdint.h>
+#include "jurassic_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { int a, b; } jur_int2;
+typedef struct { float u, eps; } jur_ue_t;
+
+/* Everything about the continua that depends on the channel only, reduced on
+ * the host once per model with the reference's own expression order
+ * (jr_common.h:318-325, 336-357, 367-372, 381-386). */
+typedef struct {
+  double nu;
+  double co2_cw296, co2_cw260, co2_cw230;   /* 2 cm^-1 grid interpolates            */
+  double h2o_sc;                            /* sfac * cw296                         */
+  double h2o_ratio;                         /* cw260 / cw296                        */
+  double h2o_ctwfrn;                        /* cwfrn * fscal                        */
+  double n2_b, n2_beta;
+  double o2_b, o2_beta;
+  int co2_on, h2o_on, n2_on, o2_on;         /* channel inside the continuum's range */
+  int window;
+  int pad;
+} jur_chan_t;
+
+/* LOS workspace: fields stored as [field][point][ray-in-chunk] (ray fastest). */
+enum { JUR_F_P = 0, JUR_F_T = 1, JUR_F_DS = 2, JUR_F_QH2O = 3, JUR_F_K = 4 /* + nw, then u[ng] */ };
+
+/* Read-only device view of a model; passed to kernels by value. */
+typedef struct {
+  int ng, nd, nw;
+  int fourbit, ig_co2, ig_h2o;
+  int refrac, write_bbt;
+  double rayds, raydz;
+  jur_chan_t const *chan;       /* [nd]                                         */
+  double const *sr;             /* [nd][JUR_TBLNS] source function              */
+  /* emissivity tables, CSR-like:
+   * pair[g*nd+d] = {np, first level}; plev/lvl per level; tval/crv per curve;
+   * ue = interleaved (u, eps) float pairs, unit stride along u. */
+  jur_int2 const *pair;
+  double const *plev;
+  jur_int2 const *lvl;          /* {nt, first curve}                            */
+  double const *tval;
+  jur_int2 const *crv;          /* {nu, first entry}                            */
+  jur_ue_t const *ue;
+  /* atmosphere, compact SoA of atm_np points */
+  int atm_np;
+  int pad;
+  double const *atm_time, *atm_z, *atm_lon, *atm_lat, *atm_p, *atm_t;
+  double const *atm_q;          /* [ng][atm_np] */
+  double const *atm_k;          /* [nw][atm_np] */
+} jur_view_t;
+
+/* One chunk of rays handed to the kernels.  All pointers are device memory and
+ * already offset to the first ray of the chunk, except `los`. */
+typedef struct {
+  int n;                        /* rays in this chunk                           */
+  int stride;                   /* R: ray stride of the LOS workspace           */
+  double const *geom[7];        /* time, obsz, obslon, obslat, vpz, vplon, vplat */
+  double *tp[3];                /* tpz, tplon, tplat                            */
+  double *rad, *tau;            /* [n][nd]                                      */
+  int *np;                      /* [n] LOS points                               */
+  double *tsurf;                /* [n]                                          */
+  double *los;                  /* [nfield][JUR_NLOS][stride]                   */
+  int *status;                  /* device flag: bit0 = NLOS overflow            */
+} jur_chunk_t;
+
+/* kernel launchers (jur_kernels.hip); return hipError_t as int */
+int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void *stream);
+int jurk_launch_integrate(jur_view_t const *v, jur_chunk_t const *c, void *stream);
+
+/* host tables (jur_tables.c) */
+typedef struct {
+  double t;
+  int nu, cap;
+  float *u, *eps;
+} jur_curve_t;
+
+typedef struct {
+  double p;
+  int nt;
+  jur_curve_t cv[JUR_TBLNT];
+} jur_level_t;
+
+typedef struct {
+  int np;                       /* 0 = no table                                 */
+  jur_level_t *lv;              /* [np]                                         */
+} jur_pair_t;
+
+struct jur_tables {
+  int ng, nd;
+  jur_pair_t *pair;             /* [ng*nd]                                      */
+  double *sr;                   /* [nd][JUR_TBLNS]                              */
+  char *have_sr;                /* [nd]                                         */
+  long ignored_rows;            /* rows dropped because a curve was full        */
+};
+
+/* flatten host tables into the CSR arrays of jur_view_t (malloc'ed) */
+typedef struct {
+  long nlevel, ncurve, nentry;
+  jur_int2 *pair;
+  double *plev;
+  jur_int2 *lvl;
+  double *tval;
+  jur_int2 *crv;
+  jur_ue_t *ue;
+} jur_flat_t;
+int  jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out);
+void jur_flat_free(jur_flat_t *f);
+
+void jur_chan_setup(jur_chan_t *ch, double nu, int window);
+void jur_set_error(char const *fmt, ...);
+
+extern const double jur_ctm_blob[] __attribute__((visibility("hidden")));
+
+#ifdef __cplusplus
+}
+#endif
+#endif

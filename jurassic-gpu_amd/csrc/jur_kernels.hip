@@ -1,0 +1,508 @@
+// jur_kernels.hip -- CDNA4 (gfx950) kernels of the JURASSIC EGA forward model.
+//
+//   jur_trace_kernel      one lane per ray: line-of-sight ray tracing through the 1-D
+//                         atmosphere (reference algorithm: jr_common.h:585-711), writes the
+//                         per-segment state p, T, ds, k, q_H2O, u[g] to the LOS workspace
+//                         in [field][point][ray] order (coalesced over rays), the tangent
+//                         point, the point count and the surface temperature.
+//   jur_integrate_kernel  one lane per (ray, channel): sequential walk along the line of
+//                         sight with continua (jr_common.h:315-390), emissivity-growth
+//                         look-ups in the band tables (jr_common.h:237-280), Planck source
+//                         (:220-224) and the radiance update (:293-300); surface term,
+//                         brightness temperature and the NaN mask are fused in the epilogue
+//                         (CPUdrivers.c:5-24, jr_common.h:193-210).
+//
+// All arithmetic is IEEE fp64 with the reference's operand order; tables are fp32 in memory.
+// Compiled with -ffp-contract=off so that no fused multiply-adds are formed that the
+// reference's x86-64 build does not form.
+
+#include <hip/hip_runtime.h>
+#include "jur_internal.h"
+
+#define NLOS JUR_NLOS
+#define TBLNS JUR_TBLNS
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// small helpers (jr_common.h:43-57)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double c01(double x) { return (x > 1.) ? 1. : ((x < 0.) ? 0. : x); }
+
+__device__ __forceinline__ double lip(double x0, double y0, double x1, double y1, double x) {
+  return y0 + (x - x0) * (y1 - y0) / (x1 - x0);
+}
+
+__device__ __forceinline__ double eip(double x0, double y0, double x1, double y1, double x) {
+  if ((y0 > 0) && (y1 > 0)) return y0 * exp(log(y1 / y0) / (x1 - x0) * (x - x0));
+  return lip(x0, y0, x1, y1, x);
+}
+
+// bracket search on an ascending or descending axis (jr_common.h:87-104)
+__device__ __forceinline__ int locate_axis(double const *__restrict__ xx, int n, double x) {
+  int ilo = 0, ihi = n - 1, i = (n - 1) >> 1;
+  if (xx[i] < xx[i + 1]) {
+    while (ihi > ilo + 1) {
+      i = (ihi + ilo) >> 1;
+      if (xx[i] > x) ihi = i; else ilo = i;
+    }
+  } else {
+    while (ihi > ilo + 1) {
+      i = (ihi + ilo) >> 1;
+      if (xx[i] <= x) ihi = i; else ilo = i;
+    }
+  }
+  return ilo;
+}
+
+// ---------------------------------------------------------------------------------------
+// geometry (jr_common.h:475-500)
+// ---------------------------------------------------------------------------------------
+#define JUR_PI 3.14159265358979323846
+#define RAD2GRD (180 / JUR_PI)
+#define GRD2RAD (JUR_PI / 180)
+
+__device__ __forceinline__ double norm3(double const x[3]) { return sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]); }
+
+__device__ __forceinline__ void cart2geo(double const x[3], double &alt, double &lon, double &lat) {
+  double const radius = norm3(x);
+  lat = asin(x[2] / radius) * RAD2GRD;
+  lon = atan2(x[1], x[0]) * RAD2GRD;
+  alt = radius - JUR_RE;
+}
+
+__device__ __forceinline__ void geo2cart(double alt, double lon, double lat, double x[3]) {
+  double const radius = alt + JUR_RE, clat = cos(lat * GRD2RAD);
+  x[0] = radius * clat * cos(lon * GRD2RAD);
+  x[1] = radius * clat * sin(lon * GRD2RAD);
+  x[2] = radius * sin(lat * GRD2RAD);
+}
+
+__device__ __forceinline__ double refractivity(double p, double t) { return 7.753e-05 * p / t; }
+
+// pressure and temperature of the profile slice [i0, i0+n) at altitude z0 (jr_common.h:549-555)
+__device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, double z0, double &p, double &t) {
+  int const ip = i0 + locate_axis(v.atm_z + i0, n, z0);
+  double const za = v.atm_z[ip], zb = v.atm_z[ip + 1];
+  p = eip(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0);
+  t = lip(za, v.atm_t[ip], zb, v.atm_t[ip + 1], z0);
+  return ip;
+}
+
+// ---------------------------------------------------------------------------------------
+// ray tracing, one lane per ray
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t c) {
+  int const r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= c.n) return;
+  size_t const R = (size_t)c.stride;
+  double *const los = c.los;
+  auto F = [&](int field, int ip) -> double & { return los[((size_t)field * NLOS + ip) * R + r]; };
+  int const f_k = JUR_F_K, f_u = JUR_F_K + v.nw;
+
+  double const time = c.geom[0][r], obsz = c.geom[1][r], obslon = c.geom[2][r], obslat = c.geom[3][r],
+               vpz = c.geom[4][r], vplon = c.geom[5][r], vplat = c.geom[6][r];
+  double tsurf = -999;
+  double tpz = vpz, tplon = vplon, tplat = vplat;
+  int np = 0;
+
+  // profile slice that carries this ray's time stamp (jr_common.h:127-154)
+  int atm0, atmn;
+  {
+    int lo = 0, hi = v.atm_np - 1;
+    while (hi > lo + 1) {
+      int const i = (lo + hi) / 2;
+      if (v.atm_time[i] < time) lo = i; else hi = i;
+    }
+    int const lower = (0 == lo) ? lo : hi;
+    lo = lower;
+    hi = v.atm_np - 1;
+    while (hi > lo + 1) {
+      int const i = (lo + hi) / 2;
+      if (v.atm_time[i] > time) hi = i; else lo = i;
+    }
+    int const upper = (hi == v.atm_np - 1) ? v.atm_np : hi;
+    atm0 = lower;
+    atmn = upper - lower;
+  }
+  // altitude range of the first column of that slice (jr_common.h:411-420)
+  double zmin = v.atm_z[atm0], zmax = zmin;
+  {
+    double const lon0 = v.atm_lon[atm0], lat0 = v.atm_lat[atm0];
+    for (int ipp = atm0; (ipp < atm0 + atmn) && (v.atm_lon[ipp] == lon0) && (v.atm_lat[ipp] == lat0); ++ipp) {
+      zmax = fmax(zmax, v.atm_z[ipp]);
+      zmin = fmin(zmin, v.atm_z[ipp]);
+    }
+  }
+
+  bool const outside = (obsz < zmin) || (vpz > zmax - 0.001);
+  if (!outside) {
+    double x[3], ex0[3], xobs[3], xvp[3];
+    geo2cart(obsz, obslon, obslat, xobs);
+    geo2cart(vpz, vplon, vplat, xvp);
+    for (int i = 0; i < 3; i++) ex0[i] = xvp[i] - xobs[i];
+    double const norm = norm3(ex0);
+    for (int i = 0; i < 3; i++) {
+      ex0[i] /= norm;
+      x[i] = xobs[i];
+    }
+    if (obsz > zmax) {  // observer above the atmosphere: bisect for the entry point (:610-621)
+      double dmax = norm, dmin = 0.;
+      while (fabs(dmin - dmax) > 0.001) {
+        double const d = 0.5 * (dmax + dmin);
+        for (int i = 0; i < 3; i++) x[i] = xobs[i] + d * ex0[i];
+        double const z = norm3(x) - JUR_RE;
+        if ((z <= zmax) && (z > zmax - 0.001)) break;
+        if (z < zmax - 0.0005) dmax = d; else dmin = d;
+      }
+    }
+
+    // bookkeeping for the tangent point: the three points around the lowest one
+    double z_low = 1e99;
+    int low_idx = -1;
+    double pz = 0, plon = 0, plat = 0;                      // previous point (np-1)
+    double lz0 = 0, llon0 = 0, llat0 = 0;                   // point low_idx-1
+    double lz1 = 0, lds1 = 0;                               // point low_idx
+    double lz2 = 0, llon2 = 0, llat2 = 0, lds2 = 0;         // point low_idx+1
+    double last_z = 0, last_lon = 0, last_lat = 0;
+
+    int stop = 0;
+    for (; np < NLOS; ++np) {
+      double ds = v.rayds;
+      double const dz = v.raydz;
+      if (dz > 0.) {
+        double const norm_x = 1.0 / norm3(x);
+        double dot = 0.;
+        for (int i = 0; i < 3; i++) dot += ex0[i] * x[i] * norm_x;
+        double const cosa = fabs(dot);
+        if (cosa != 0.) ds = fmin(ds, dz / cosa);
+      }
+      double z, lon, lat;
+      cart2geo(x, z, lon, lat);
+      if ((z < zmin) || (z > zmax)) {  // LOS left the atmosphere: clip the last segment (:637-648)
+        double xh[3];
+        stop = (z < zmin) ? 2 : 1;
+        if (np > 0) {
+          geo2cart(pz, plon, plat, xh);
+          double const zfrac = (z < zmin) ? zmin : zmax;
+          double const frac = (zfrac - pz) / (z - pz);
+          for (int i = 0; i < 3; i++) x[i] = xh[i] + frac * (x[i] - xh[i]);
+          cart2geo(x, z, lon, lat);
+          double const dsp = ds * frac;
+          F(JUR_F_DS, np - 1) = dsp;
+          if (low_idx == np - 1) lds1 = dsp;
+          if (low_idx + 1 == np - 1) lds2 = dsp;
+        }
+        ds = 0.;
+      }
+
+      double p, t;
+      int const ia = intpol_pt(v, atm0, atmn, z, p, t);
+      {  // remaining quantities on the same bracket (jr_common.h:557-567)
+        double const za = v.atm_z[ia], zb = v.atm_z[ia + 1];
+        for (int ig = 0; ig < v.ng; ig++) {
+          double const *q = v.atm_q + (size_t)ig * v.atm_np;
+          double const qv = lip(za, q[ia], zb, q[ia + 1], z);
+          F(f_u + ig, np) = qv;  // mixing ratio now, column density after the trapezoid pass
+          if (ig == v.ig_h2o) F(JUR_F_QH2O, np) = qv;
+        }
+        for (int iw = 0; iw < v.nw; iw++) {
+          double const *k = v.atm_k + (size_t)iw * v.atm_np;
+          F(f_k + iw, np) = lip(za, k[ia], zb, k[ia + 1], z);
+        }
+      }
+      F(JUR_F_P, np) = p;
+      F(JUR_F_T, np) = t;
+      F(JUR_F_DS, np) = ds;
+
+      if (low_idx >= 0 && low_idx == np - 1) { lz2 = z; llon2 = lon; llat2 = lat; lds2 = ds; }
+      if (z < z_low) {
+        z_low = z;
+        low_idx = np;
+        lz0 = pz; llon0 = plon; llat0 = plat;
+        lz1 = z; lds1 = ds;
+      }
+      last_z = z; last_lon = lon; last_lat = lat;
+      pz = z; plon = lon; plat = lat;
+
+      if (stop) {
+        tsurf = (stop == 2 ? t : -999);
+        break;
+      }
+
+      double n = 1., ngr[3] = {0., 0., 0.};
+      if (v.refrac && z <= 60.) {  // refractivity gradient by finite differences (:665-681)
+        n += refractivity(p, t);
+        double xh[3], zz, llon, llat, pp, tt;
+        for (int i = 0; i < 3; i++) xh[i] = x[i] + 0.5 * ds * ex0[i];
+        cart2geo(xh, zz, llon, llat);
+        intpol_pt(v, atm0, atmn, zz, pp, tt);
+        double const n2 = refractivity(pp, tt);
+        for (int i = 0; i < 3; i++) {
+          double const h = 0.02;
+          xh[i] += h;
+          cart2geo(xh, zz, llon, llat);
+          intpol_pt(v, atm0, atmn, zz, pp, tt);
+          ngr[i] = (refractivity(pp, tt) - n2) / h;
+          xh[i] -= h;
+        }
+      }
+      double ex1[3];
+      for (int i = 0; i < 3; i++) ex1[i] = ex0[i] * n + ds * ngr[i];
+      double const norm_ex1 = norm3(ex1);
+      for (int i = 0; i < 3; i++) {
+        ex1[i] /= norm_ex1;
+        x[i] += 0.5 * ds * (ex0[i] + ex1[i]);
+        ex0[i] = ex1[i];
+      }
+    }
+    ++np;
+    if (NLOS <= np) {  // the reference aborts here (jr_common.h:693-695); flag and clamp
+      atomicOr(c.status, 1);
+      np = NLOS - 1;
+    }
+
+    // tangent point from the raw segment lengths (jr_common.h:502-539)
+    if (low_idx <= 0 || low_idx >= np - 1) {
+      tpz = last_z; tplon = last_lon; tplat = last_lat;
+    } else {
+      double const yy0 = lz0, yy1 = lz1, yy2 = lz2, ds0 = lds1, ds1 = lds2,
+                   dyy10 = yy1 - yy0, dyy21 = yy2 - yy1,
+                   x1 = sqrt(ds0 * ds0 - dyy10 * dyy10),
+                   x2 = x1 + sqrt(ds1 * ds1 - dyy21 * dyy21),
+                   dx12 = x1 - x2,
+                   a = (dyy10 * x2 + (yy0 - yy2) * x1) / (x1 * x2 * dx12),
+                   b = dyy10 / x1 - a * x1,
+                   cc = yy0,
+                   xt = -b / (2 * a);
+      tpz = (a * xt + b) * xt + cc;
+      double w[3], v0[3], v2[3], dummy;
+      geo2cart(lz0, llon0, llat0, v0);
+      geo2cart(lz2, llon2, llat2, v2);
+      for (int i = 0; i < 3; i++) w[i] = lip(0.0, v0[i], x2, v2[i], xt);
+      cart2geo(w, dummy, tplon, tplat);
+    }
+
+    // trapezoid rule on ds (descending, jr_common.h:437-443), then column densities (:446-453)
+    for (int ip = np - 1; ip >= 0; ip--) {
+      double const dsr = F(JUR_F_DS, ip);
+      double const dsn = (ip >= 1) ? 0.5 * (F(JUR_F_DS, ip - 1) + dsr) : dsr * 0.5;
+      F(JUR_F_DS, ip) = dsn;
+      double const p = F(JUR_F_P, ip), t = F(JUR_F_T, ip);
+      for (int ig = 0; ig < v.ng; ig++) {
+        double const q = F(f_u + ig, ip);
+        F(f_u + ig, ip) = 10. * q * p / (JUR_BOLTZMANN * t) * dsn;
+      }
+    }
+  }
+
+  c.np[r] = np;
+  c.tsurf[r] = tsurf;
+  c.tp[0][r] = tpz;
+  c.tp[1][r] = tplon;
+  c.tp[2][r] = tplat;
+}
+
+// ---------------------------------------------------------------------------------------
+// emissivity-growth look-up
+// ---------------------------------------------------------------------------------------
+// ascending-only bracket search on a double axis (locate_id, jr_common.h:106-114)
+__device__ __forceinline__ int locate_up(double const *__restrict__ xx, int n, double x) {
+  int ilo = 0, ihi = n - 1;
+  while (ihi > ilo + 1) {
+    int const i = (ihi + ilo) >> 1;
+    if (xx[i] > x) ihi = i; else ilo = i;
+  }
+  return ilo;
+}
+
+// u at which curve `e` reaches emissivity eps (get_u, jr_common.h:179-185)
+__device__ __forceinline__ double curve_u_of_eps(jur_ue_t const *__restrict__ e, int n, double eps) {
+  int ilo = 0, ihi = n - 1;
+  while (ihi > ilo + 1) {
+    int const i = (ihi + ilo) >> 1;
+    if ((double)e[i].eps > eps) ihi = i; else ilo = i;
+  }
+  jur_ue_t const a = e[ilo], b = e[ilo + 1];
+  return lip((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps);
+}
+
+// emissivity of curve `e` at column density u (get_eps, jr_common.h:156-177)
+__device__ __forceinline__ double curve_eps_of_u(jur_ue_t const *__restrict__ e, int n, double u) {
+  int ilo = 0, ihi = n - 1;
+  while (ihi > ilo + 1) {
+    int const i = (ihi + ilo) >> 1;
+    if ((double)e[i].u > u) ihi = i; else ilo = i;
+  }
+  jur_ue_t const a = e[ilo], b = e[ilo + 1];
+  return lip((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, u);
+}
+
+// segment transmittance of gas g in channel d given the transmittance accumulated so far
+// (ega_eps, jr_common.h:237-268)
+__device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, double tau, double t, double u, double p) {
+  if (tau < 1e-9) return 0.;
+  jur_int2 const pr = v.pair[pair_idx];
+  if (pr.a < 2) return 1.;
+  double const *pl = v.plev + pr.b;
+  int const ipr = locate_up(pl, pr.a, p);
+  jur_int2 const l0 = v.lvl[pr.b + ipr], l1 = v.lvl[pr.b + ipr + 1];
+  if (l0.a < 2 || l1.a < 2) return 1.;
+  double const *t0 = v.tval + l0.b, *t1 = v.tval + l1.b;
+  int const it0 = locate_up(t0, l0.a, t);
+  jur_int2 const c00 = v.crv[l0.b + it0], c01_ = v.crv[l0.b + it0 + 1];
+  if (c00.a < 2 || c01_.a < 2) return 1.;
+  int const it1 = locate_up(t1, l1.a, t);
+  jur_int2 const c10 = v.crv[l1.b + it1], c11 = v.crv[l1.b + it1 + 1];
+  if (c10.a < 2 || c11.a < 2) return 1.;
+
+  double const eps = 1 - tau;
+  jur_ue_t const *e00 = v.ue + c00.b, *e01 = v.ue + c01_.b, *e10 = v.ue + c10.b, *e11 = v.ue + c11.b;
+  double const u00 = curve_u_of_eps(e00, c00.a, eps);
+  double const u01 = curve_u_of_eps(e01, c01_.a, eps);
+  double const u10 = curve_u_of_eps(e10, c10.a, eps);
+  double const u11 = curve_u_of_eps(e11, c11.a, eps);
+
+  double const eps00 = c01(curve_eps_of_u(e00, c00.a, u00 + u));
+  double const eps01 = c01(curve_eps_of_u(e01, c01_.a, u01 + u));
+  double const eps10 = c01(curve_eps_of_u(e10, c10.a, u10 + u));
+  double const eps11 = c01(curve_eps_of_u(e11, c11.a, u11 + u));
+
+  double const eps_p0 = c01(lip(t0[it0], eps00, t0[it0 + 1], eps01, t));
+  double const eps_p1 = c01(lip(t1[it1], eps10, t1[it1 + 1], eps11, t));
+  double const eps_t = c01(lip(pl[ipr], eps_p0, pl[ipr + 1], eps_p1, p));
+  return (1. - eps_t) / tau;
+}
+
+// ---------------------------------------------------------------------------------------
+// continua; the channel-only factors come precomputed in jur_chan_t
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double ctm_co2(jur_chan_t const &ch, double p, double t, double u) {
+  double const dt230 = t - 230;
+  double const dt260 = t - 260;
+  double const dt296 = t - 296;
+  double const ctw = dt260 * 5.050505e-4 * dt296 * ch.co2_cw230 - dt230 * 9.259259e-4 * dt296 * ch.co2_cw260
+                   + dt230 * 4.208754e-4 * dt260 * ch.co2_cw296;
+  return u * p * ctw / (JUR_AVOGADRO * 1000 * JUR_P0);
+}
+
+__device__ __forceinline__ double ctm_h2o(jur_chan_t const &ch, double p, double t, double q, double u) {
+  double const ctwslf = ch.h2o_sc * pow(ch.h2o_ratio, (296. - t) / (296. - 260.));
+  double const a1 = ch.nu * u * tanh(.7193876 / t * ch.nu);
+  double const a2 = 296. / t;
+  double const a3 = p / JUR_P0 * (q * ctwslf + (1 - q) * ch.h2o_ctwfrn) * 1e-20;
+  return a1 * a2 * a3;
+}
+
+__device__ __forceinline__ double ctm_n2(jur_chan_t const &ch, double p, double t) {
+  double const q_n2 = 0.79, t0 = 273, tr = 296;
+  return 0.1 * (p / JUR_P0) * (p / JUR_P0) * (t0 / t) * (t0 / t) * exp(ch.n2_beta * (1 / tr - 1 / t)) * q_n2 * ch.n2_b
+         * (q_n2 + (1 - q_n2) * (1.294 - 0.4545 * t / tr));
+}
+
+__device__ __forceinline__ double ctm_o2(jur_chan_t const &ch, double p, double t) {
+  double const q_o2 = 0.21, t0 = 273, tr = 296;
+  return 0.1 * (p / JUR_P0) * (p / JUR_P0) * (t0 / t) * (t0 / t) * exp(ch.o2_beta * (1 / tr - 1 / t)) * q_o2 * ch.o2_b;
+}
+
+__device__ __forceinline__ double planck_src(double const *__restrict__ sr, double t) {
+  int const it = (int)(4 * t) - 400;  // 0.25 K grid from 100 K (jr_common.h:82-84; no range check upstream)
+  double const st0 = 100 + ((double)it - 0.0) * (400 - 100) / ((TBLNS - 1.0) - 0.0);
+  double const st1 = 100 + ((double)(it + 1) - 0.0) * (400 - 100) / ((TBLNS - 1.0) - 0.0);
+  return lip(st0, sr[it], st1, sr[it + 1], t);
+}
+
+// ---------------------------------------------------------------------------------------
+// along-path integration, one lane per (ray, channel)
+// ---------------------------------------------------------------------------------------
+template <int NGT>
+__global__ __launch_bounds__(256) void jur_integrate_kernel(jur_view_t v, jur_chunk_t c) {
+  long const lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int const nd = v.nd;
+  if (lane >= (long)c.n * nd) return;
+  int const r = (int)(lane / nd), d = (int)(lane - (long)r * nd);
+  size_t const R = (size_t)c.stride;
+  double const *const los = c.los;
+  jur_chan_t const ch = v.chan[d];
+  double const *const sr = v.sr + (size_t)d * TBLNS;
+  int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
+  int const ng = v.ng;
+  bool const do_co2 = (v.fourbit & 8) && ch.co2_on, do_h2o = (v.fourbit & 4) && ch.h2o_on,
+             do_n2 = (v.fourbit & 2) && ch.n2_on, do_o2 = (v.fourbit & 1) && ch.o2_on;
+
+  bool const masked = !isfinite(c.rad[lane]);
+  double rad = 0.0, tau = 1.0;
+  double tau_path[NGT];
+#pragma unroll
+  for (int g = 0; g < NGT; g++) tau_path[g] = 1.0;
+
+  int const np = c.np[r];
+  for (int ip = 0; ip < np; ++ip) {
+    size_t const o = (size_t)ip * R + r;
+    size_t const fs = (size_t)NLOS * R;
+    double const p = los[JUR_F_P * fs + o], t = los[JUR_F_T * fs + o], ds = los[JUR_F_DS * fs + o];
+
+    // extinction and continua (jr_continua_core.mv4g.h:1-14)
+    double beta_ds = los[f_k * fs + o] * ds;
+    if (do_co2) beta_ds += ctm_co2(ch, p, t, los[(f_u + v.ig_co2) * fs + o]);
+    if (do_h2o) beta_ds += ctm_h2o(ch, p, t, los[JUR_F_QH2O * fs + o], los[(f_u + v.ig_h2o) * fs + o]);
+    if (do_n2) beta_ds += ctm_n2(ch, p, t) * ds;
+    if (do_o2) beta_ds += ctm_o2(ch, p, t) * ds;
+
+    // gas transmittance of the segment by emissivity growth (jr_common.h:270-280)
+    double tau_gas = 1.0;
+#pragma unroll
+    for (int g = 0; g < NGT; g++) {
+      if (g < ng) {
+        double const eps = ega_eps(v, g * nd + d, tau_path[g], t, los[(f_u + g) * fs + o], p);
+        tau_path[g] *= eps;
+        tau_gas *= eps;
+      }
+    }
+
+    double const src = planck_src(sr, t);
+    if (tau_gas > 1e-50) {  // jr_common.h:293-300
+      double const eps = 1. - tau_gas * exp(-beta_ds);
+      rad += src * eps * tau;
+      tau *= (1. - eps);
+    }
+  }
+
+  double const tsurf = c.tsurf[r];
+  if (tsurf > 0.) rad += planck_src(sr, tsurf) * tau;  // jr_common.h:227-234
+  if (v.write_bbt) rad = JUR_C2 * ch.nu / log1p((JUR_C1 * ch.nu * ch.nu * ch.nu) / rad);  // :188-190
+  if (masked) rad = __builtin_nan("");
+  c.rad[lane] = rad;
+  c.tau[lane] = tau;
+}
+
+}  // namespace
+
+extern "C" int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
+  if (c->n <= 0) return 0;
+  int const block = 64;
+  int const grid = (c->n + block - 1) / block;
+  hipLaunchKernelGGL(jur_trace_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *v, *c);
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_launch_integrate(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
+  if (c->n <= 0) return 0;
+  int const block = 256;
+  long const lanes = (long)c->n * v->nd;
+  int const grid = (int)((lanes + block - 1) / block);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(N) hipLaunchKernelGGL(jur_integrate_kernel<N>, dim3(grid), dim3(block), 0, s, *v, *c)
+  if (v->ng <= 1) LAUNCH(1);
+  else if (v->ng <= 2) LAUNCH(2);
+  else if (v->ng <= 3) LAUNCH(3);
+  else if (v->ng <= 4) LAUNCH(4);
+  else if (v->ng <= 5) LAUNCH(5);
+  else if (v->ng <= 6) LAUNCH(6);
+  else if (v->ng <= 8) LAUNCH(8);
+  else if (v->ng <= 12) LAUNCH(12);
+  else if (v->ng <= 16) LAUNCH(16);
+  else LAUNCH(JUR_NG);
+#undef LAUNCH
+  return (int)hipGetLastError();
+}

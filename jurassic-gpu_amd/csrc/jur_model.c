@@ -1,0 +1,475 @@
+/* jur_model.c -- host orchestration: device residency of a model, the batched
+ * formod entry points and the drop-in formod()/formod_GPU()/formod_pencil().
+ *
+ * Plain C over the HIP runtime C API.  There is deliberately no CPU fallback:
+ * without a GPU every entry point fails loudly.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <pthread.h>
+#include <hip/hip_runtime_api.h>
+#include "jur_internal.h"
+
+#define HIPCHK(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      jur_set_error("HIP error %d (%s) at %s:%d", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return JUR_EHIP;                                                                     \
+    }                                                                                      \
+  } while (0)
+
+struct jur_model {
+  int device;
+  ctl_t *ctl;                   /* private copy of the control block             */
+  jur_view_t view;              /* device pointers                               */
+  long table_bytes;
+  /* device allocations owned by the model */
+  void *d_chan, *d_sr, *d_pair, *d_plev, *d_lvl, *d_tval, *d_crv, *d_ue;
+  void *d_atm;                  /* one slab for the compact atmosphere           */
+  int atm_cap;
+  /* per-call workspace */
+  int chunk_rays;               /* R                                             */
+  int nfield;
+  double *d_los;
+  int *d_np;
+  double *d_tsurf;
+  int *d_status;
+  long los_bytes;
+  /* staging for the host entry */
+  double *d_io;                 /* geom[7][cap] tp[3][cap] rad/tau[cap][nd]      */
+  int *d_io_np;
+  long io_cap;
+  hipStream_t stream;
+  /* timing */
+  int timing;
+  hipEvent_t *evpool;           /* 3 events per timed chunk                      */
+  int ntimed;
+};
+
+#define JUR_MAX_TIMED 1024
+
+static int find_emitter(ctl_t const *ctl, char const *name) {
+  for (int ig = 0; ig < ctl->ng; ig++)
+    if (0 == strcasecmp(ctl->emitter[ig], name)) return ig;
+  return -1;
+}
+
+static int upload(void **dst, void const *src, size_t bytes) {
+  if (bytes == 0) bytes = 8;
+  HIPCHK(hipMalloc(dst, bytes));
+  if (src) HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return JUR_OK;
+}
+
+static int check_ctl(ctl_t const *ctl) {
+  if (ctl->ng < 0 || ctl->ng > JUR_NG) { jur_set_error("ctl->ng=%d outside 0..%d", ctl->ng, JUR_NG); return JUR_EINVAL; }
+  if (ctl->nd < 1 || ctl->nd > JUR_ND) { jur_set_error("ctl->nd=%d outside 1..%d", ctl->nd, JUR_ND); return JUR_EINVAL; }
+  if (ctl->nw < 0 || ctl->nw > JUR_NW) { jur_set_error("ctl->nw=%d outside 0..%d", ctl->nw, JUR_NW); return JUR_EINVAL; }
+  if (ctl->ip != 1) { jur_set_error("only 1-D profile interpolation is supported (ctl->ip == 1, as upstream asserts)"); return JUR_EINVAL; }
+  if (ctl->formod == 1) { jur_set_error("FORMOD=1 (CGA) has no integrator upstream either"); return JUR_EINVAL; }
+  for (int id = 0; id < ctl->nd; id++)
+    if (ctl->window[id] < 0 || ctl->window[id] >= (ctl->nw > 0 ? ctl->nw : 1)) { jur_set_error("ctl->window[%d] out of range", id); return JUR_EINVAL; }
+  return JUR_OK;
+}
+
+int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb, int device) {
+  *out = NULL;
+  int rc = check_ctl(ctl);
+  if (rc) return rc;
+  if (!tb || tb->ng < ctl->ng || tb->nd < ctl->nd) { jur_set_error("tables do not cover ctl (ng, nd)"); return JUR_EINVAL; }
+  for (int id = 0; id < ctl->nd; id++)
+    if (!tb->have_sr[id]) { jur_set_error("no filter function / source table for channel %d", id); return JUR_EINVAL; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { jur_set_error("no HIP device available"); return JUR_ENODEV; }
+  if (device < 0 || device >= ndev) { jur_set_error("device %d not in 0..%d", device, ndev - 1); return JUR_ENODEV; }
+  HIPCHK(hipSetDevice(device));
+
+  jur_model_t *m = (jur_model_t *)calloc(1, sizeof *m);
+  if (!m) return JUR_ENOMEM;
+  m->device = device;
+  m->ctl = (ctl_t *)malloc(sizeof(ctl_t));
+  memcpy(m->ctl, ctl, sizeof(ctl_t));
+  jur_view_t *v = &m->view;
+  v->ng = ctl->ng; v->nd = ctl->nd; v->nw = ctl->nw > 0 ? ctl->nw : 1;
+  v->refrac = ctl->refrac; v->write_bbt = ctl->write_bbt;
+  v->rayds = ctl->rayds; v->raydz = ctl->raydz;
+  /* continuum switches, CPUdrivers.c:126-134 */
+  v->ig_co2 = -999; v->ig_h2o = -999;
+  if (ctl->ctm_h2o) v->ig_h2o = find_emitter(ctl, "H2O");
+  if (ctl->ctm_co2) v->ig_co2 = find_emitter(ctl, "CO2");
+  v->fourbit = ((1 == ctl->ctm_co2) && (v->ig_co2 >= 0)) * 8 + ((1 == ctl->ctm_h2o) && (v->ig_h2o >= 0)) * 4
+             + (1 == ctl->ctm_n2) * 2 + (1 == ctl->ctm_o2) * 1;
+
+  jur_chan_t *chan = (jur_chan_t *)calloc(ctl->nd, sizeof(jur_chan_t));
+  for (int id = 0; id < ctl->nd; id++) jur_chan_setup(&chan[id], ctl->nu[id], ctl->window[id]);
+  rc = upload(&m->d_chan, chan, sizeof(jur_chan_t) * ctl->nd);
+  free(chan);
+  if (rc) { jur_model_destroy(m); return rc; }
+  if ((rc = upload(&m->d_sr, tb->sr, sizeof(double) * JUR_TBLNS * ctl->nd))) { jur_model_destroy(m); return rc; }
+
+  /* tables restricted to the (ng, nd) the control block uses */
+  jur_tables_t sub = *tb;
+  jur_pair_t *subpair = NULL;
+  if (tb->nd != ctl->nd || tb->ng != ctl->ng) {
+    subpair = (jur_pair_t *)calloc((size_t)ctl->ng * ctl->nd + 1, sizeof(jur_pair_t));
+    for (int g = 0; g < ctl->ng; g++)
+      for (int d = 0; d < ctl->nd; d++) subpair[(size_t)g * ctl->nd + d] = tb->pair[(size_t)g * tb->nd + d];
+    sub.pair = subpair; sub.ng = ctl->ng; sub.nd = ctl->nd;
+  }
+  jur_flat_t fl;
+  rc = jur_tables_flatten(&sub, &fl);
+  free(subpair);
+  if (rc) { jur_model_destroy(m); return rc; }
+  long const npair = (long)ctl->ng * ctl->nd;
+  rc = upload(&m->d_pair, fl.pair, sizeof(jur_int2) * (npair > 0 ? npair : 1));
+  if (!rc) rc = upload(&m->d_plev, fl.plev, sizeof(double) * (fl.nlevel + 1));
+  if (!rc) rc = upload(&m->d_lvl, fl.lvl, sizeof(jur_int2) * (fl.nlevel + 1));
+  if (!rc) rc = upload(&m->d_tval, fl.tval, sizeof(double) * (fl.ncurve + 1));
+  if (!rc) rc = upload(&m->d_crv, fl.crv, sizeof(jur_int2) * (fl.ncurve + 1));
+  if (!rc) rc = upload(&m->d_ue, fl.ue, sizeof(jur_ue_t) * (fl.nentry + 2));
+  m->table_bytes = (long)(sizeof(jur_ue_t) * fl.nentry + 16 * fl.ncurve + 16 * fl.nlevel + 8 * npair);
+  jur_flat_free(&fl);
+  if (rc) { jur_model_destroy(m); return rc; }
+  v->chan = (jur_chan_t const *)m->d_chan;
+  v->sr = (double const *)m->d_sr;
+  v->pair = (jur_int2 const *)m->d_pair;
+  v->plev = (double const *)m->d_plev;
+  v->lvl = (jur_int2 const *)m->d_lvl;
+  v->tval = (double const *)m->d_tval;
+  v->crv = (jur_int2 const *)m->d_crv;
+  v->ue = (jur_ue_t const *)m->d_ue;
+
+  m->nfield = JUR_F_K + v->nw + v->ng;
+  m->chunk_rays = 131072;
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { jur_set_error("hipStreamCreate failed"); jur_model_destroy(m); return JUR_EHIP; }
+  if ((rc = upload((void **)&m->d_status, NULL, sizeof(int)))) { jur_model_destroy(m); return rc; }
+  HIPCHK(hipMemset(m->d_status, 0, sizeof(int)));
+  *out = m;
+  return JUR_OK;
+}
+
+int jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device) {
+  *out = NULL;
+  int rc = check_ctl(ctl);
+  if (rc) return rc;
+  jur_tables_t *tb = jur_tables_new(ctl->ng, ctl->nd);
+  if (!tb) return JUR_ENOMEM;
+  rc = jur_tables_read_ascii(tb, ctl);
+  if (rc >= 0) {
+    int const found = rc;
+    if (found < ctl->ng * ctl->nd) printf("Warning! %d files were not found!\n", ctl->ng * ctl->nd - found);
+    rc = jur_tables_read_filters(tb, ctl);
+  }
+  if (rc == JUR_OK) rc = jur_model_create(out, ctl, tb, device);
+  jur_tables_free(tb);
+  return rc;
+}
+
+void jur_model_destroy(jur_model_t *m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_plev, m->d_lvl, m->d_tval, m->d_crv, m->d_ue, m->d_atm,
+                  m->d_los, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np};
+  for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
+    if (ptrs[i]) (void)hipFree(ptrs[i]);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  if (m->evpool) {
+    for (int i = 0; i < 3 * JUR_MAX_TIMED; i++) (void)hipEventDestroy(m->evpool[i]);
+    free(m->evpool);
+  }
+  free(m->ctl);
+  free(m);
+}
+
+/* ---- hydrostatic adjustment on the host (jr_common.h:212-217, 713-761) ------ */
+static double gravity(double z, double lat) {
+  double const deg2rad = M_PI / 180., x = sin(lat * deg2rad), y = sin(2 * lat * deg2rad);
+  return 9.780318 * (1. + 0.0053024 * x * x - 5.8e-6 * y * y) - 3.086e-3 * z;
+}
+
+static double lin(double x0, double y0, double x1, double y1, double x) { return y0 + (x - x0) * (y1 - y0) / (x1 - x0); }
+
+static void layer_pressure(double const *z, double const *t, double const *qh2o, double *p, double lat, int from, int to) {
+  /* integrates the hydrostatic equation across one layer with 20 sub-points */
+  int const npts = 20;
+  double const mmair = 28.96456e-3, mmh2o = 18.0153e-3;
+  double mean = 0., e = 0.;
+  for (int i = 0; i < npts; i++) {
+    double const zz = lin(0.0, z[from], npts - 1.0, z[to], (double)i);
+    double const grav = gravity(zz, lat);
+    if (qh2o) e = lin(0.0, qh2o[from], npts - 1.0, qh2o[to], (double)i);
+    double const temp = lin(0.0, t[from], npts - 1.0, t[to], (double)i);
+    mean += (e * mmh2o + (1 - e) * mmair) * grav / (JUR_MOLAR_GAS * temp * npts);
+  }
+  p[to] = p[from] * exp(-1000 * mean * (z[to] - z[from]));
+}
+
+static void hydrostatic(ctl_t const *ctl, int ig_h2o, int n, double const *z, double const *lat, double const *t,
+                        double const *qh2o, double *p) {
+  double dzmin = 1e99;
+  int ipref = 0;
+  for (int ip = 0; ip < n; ip++) {
+    double const dz = fabs(z[ip] - ctl->hydz);
+    if (dz < dzmin) { dzmin = dz; ipref = ip; }
+  }
+  double const *q = (ig_h2o >= 0) ? qh2o : NULL;
+  for (int ip = ipref + 1; ip < n; ip++) layer_pressure(z, t, q, p, lat[ipref], ip - 1, ip);
+  for (int ip = ipref - 1; ip >= 0; ip--) layer_pressure(z, t, q, p, lat[ipref], ip + 1, ip);
+}
+
+int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
+  if (!m || !atm || atm->np < 2 || atm->np > JUR_NP) { jur_set_error("set_atm: need 2..%d atmospheric points", JUR_NP); return JUR_EINVAL; }
+  HIPCHK(hipSetDevice(m->device));
+  jur_view_t *v = &m->view;
+  int const n = atm->np, ng = v->ng, nw = v->nw;
+  size_t const nrow = 6 + (size_t)ng + nw;
+  double *h = (double *)malloc(sizeof(double) * nrow * n);
+  if (!h) return JUR_ENOMEM;
+  memcpy(h + 0 * (size_t)n, atm->time, sizeof(double) * n);
+  memcpy(h + 1 * (size_t)n, atm->z, sizeof(double) * n);
+  memcpy(h + 2 * (size_t)n, atm->lon, sizeof(double) * n);
+  memcpy(h + 3 * (size_t)n, atm->lat, sizeof(double) * n);
+  memcpy(h + 4 * (size_t)n, atm->p, sizeof(double) * n);
+  memcpy(h + 5 * (size_t)n, atm->t, sizeof(double) * n);
+  for (int g = 0; g < ng; g++) memcpy(h + (6 + (size_t)g) * n, atm->q[g], sizeof(double) * n);
+  for (int w = 0; w < nw; w++) memcpy(h + (6 + (size_t)ng + w) * n, atm->k[w], sizeof(double) * n);
+  if (!(m->ctl->hydz < 0))  /* CPUdrivers.c:98-103; applied to the private copy */
+    hydrostatic(m->ctl, v->ig_h2o, n, h + 1 * (size_t)n, h + 3 * (size_t)n, h + 5 * (size_t)n,
+                v->ig_h2o >= 0 ? h + (6 + (size_t)v->ig_h2o) * n : NULL, h + 4 * (size_t)n);
+  if (n > m->atm_cap) {
+    if (m->d_atm) (void)hipFree(m->d_atm);
+    m->d_atm = NULL;
+    hipError_t e = hipMalloc(&m->d_atm, sizeof(double) * nrow * n);
+    if (e != hipSuccess) { free(h); jur_set_error("hipMalloc(atm) failed"); return JUR_EHIP; }
+    m->atm_cap = n;
+  }
+  /* ordered behind earlier work on the model's stream */
+  hipError_t e = hipMemcpyAsync(m->d_atm, h, sizeof(double) * nrow * n, hipMemcpyHostToDevice, m->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+  free(h);
+  if (e != hipSuccess) { jur_set_error("atm upload failed: %s", hipGetErrorString(e)); return JUR_EHIP; }
+  double const *d = (double const *)m->d_atm;
+  v->atm_np = n;
+  v->atm_time = d; v->atm_z = d + (size_t)n; v->atm_lon = d + 2 * (size_t)n; v->atm_lat = d + 3 * (size_t)n;
+  v->atm_p = d + 4 * (size_t)n; v->atm_t = d + 5 * (size_t)n;
+  v->atm_q = d + 6 * (size_t)n; v->atm_k = d + (6 + (size_t)ng) * n;
+  return JUR_OK;
+}
+
+/* ---- workspace --------------------------------------------------------------- */
+static int ensure_workspace(jur_model_t *m, long nr) {
+  long R = m->chunk_rays;
+  if (nr < R) R = (nr + 63) / 64 * 64;
+  if (R < 64) R = 64;
+  long const need = (long)sizeof(double) * m->nfield * JUR_NLOS * R;
+  if (need > m->los_bytes) {
+    if (m->d_los) (void)hipFree(m->d_los);
+    if (m->d_np) (void)hipFree(m->d_np);
+    if (m->d_tsurf) (void)hipFree(m->d_tsurf);
+    m->d_los = NULL; m->d_np = NULL; m->d_tsurf = NULL; m->los_bytes = 0;
+    HIPCHK(hipMalloc((void **)&m->d_los, need));
+    HIPCHK(hipMalloc((void **)&m->d_np, sizeof(int) * R));
+    HIPCHK(hipMalloc((void **)&m->d_tsurf, sizeof(double) * R));
+    m->los_bytes = need;
+  }
+  return JUR_OK;
+}
+
+long jur_model_workspace_bytes(jur_model_t const *m) { return m->los_bytes; }
+int jur_model_chunk_rays(jur_model_t const *m) { return m->chunk_rays; }
+
+int jur_model_set_chunk_rays(jur_model_t *m, int rays) {
+  if (rays < 64 || rays > (1 << 22)) { jur_set_error("chunk_rays must be in 64..4194304"); return JUR_EINVAL; }
+  m->chunk_rays = (rays + 63) / 64 * 64;
+  return JUR_OK;
+}
+
+int jur_model_enable_timing(jur_model_t *m, int on) {
+  HIPCHK(hipSetDevice(m->device));
+  if (on && !m->evpool) {
+    m->evpool = (hipEvent_t *)calloc(3 * JUR_MAX_TIMED, sizeof(hipEvent_t));
+    if (!m->evpool) return JUR_ENOMEM;
+    for (int i = 0; i < 3 * JUR_MAX_TIMED; i++) HIPCHK(hipEventCreate(&m->evpool[i]));
+  }
+  m->timing = on;
+  m->ntimed = 0;
+  return JUR_OK;
+}
+
+/* Sums the event-bracketed durations of the launches recorded since the last
+ * call (at most JUR_MAX_TIMED chunks), then starts over. */
+int jur_model_last_kernel_ms(jur_model_t *m, double out_ms[2], long out_launches[2]) {
+  out_ms[0] = out_ms[1] = 0;
+  out_launches[0] = out_launches[1] = 0;
+  if (!m->evpool) return JUR_OK;
+  HIPCHK(hipSetDevice(m->device));
+  for (int i = 0; i < m->ntimed; i++) {
+    float ms = 0;
+    HIPCHK(hipEventSynchronize(m->evpool[3 * i + 2]));
+    HIPCHK(hipEventElapsedTime(&ms, m->evpool[3 * i], m->evpool[3 * i + 1]));
+    out_ms[0] += ms; out_launches[0]++;
+    HIPCHK(hipEventElapsedTime(&ms, m->evpool[3 * i + 1], m->evpool[3 * i + 2]));
+    out_ms[1] += ms; out_launches[1]++;
+  }
+  m->ntimed = 0;
+  return JUR_OK;
+}
+
+/* ---- forward model ------------------------------------------------------------ */
+int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_rad, double *d_tau, double *d_tp,
+                      int *d_np, int *d_status, void *stream) {
+  if (!m || nr < 0) { jur_set_error("formod_device: bad arguments"); return JUR_EINVAL; }
+  if (nr == 0) return JUR_OK;
+  if (m->view.atm_np < 2) { jur_set_error("formod_device: no atmosphere set"); return JUR_EINVAL; }
+  HIPCHK(hipSetDevice(m->device));
+  int rc = ensure_workspace(m, nr);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  long const R = m->los_bytes / ((long)sizeof(double) * m->nfield * JUR_NLOS);
+  int const nd = m->view.nd;
+  for (long r0 = 0; r0 < nr; r0 += R) {
+    jur_chunk_t c;
+    c.n = (int)((nr - r0 < R) ? nr - r0 : R);
+    c.stride = (int)R;
+    for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * nr + r0;
+    for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * nr + r0;
+    c.rad = d_rad + (size_t)r0 * nd;
+    c.tau = d_tau + (size_t)r0 * nd;
+    c.np = d_np ? d_np + r0 : m->d_np;
+    c.tsurf = m->d_tsurf;
+    c.los = m->d_los;
+    c.status = d_status ? d_status : m->d_status;
+    hipEvent_t *ev = (m->timing && m->ntimed < JUR_MAX_TIMED) ? m->evpool + 3 * m->ntimed : NULL;
+    if (ev) HIPCHK(hipEventRecord(ev[0], s));
+    int e = jurk_launch_trace(&m->view, &c, s);
+    if (e) { jur_set_error("trace kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
+    if (ev) HIPCHK(hipEventRecord(ev[1], s));
+    e = jurk_launch_integrate(&m->view, &c, s);
+    if (e) { jur_set_error("integrate kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
+    if (ev) {
+      HIPCHK(hipEventRecord(ev[2], s));
+      m->ntimed++;
+    }
+  }
+  return JUR_OK;
+}
+
+int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double *rad, double *tau, double *const tp[3],
+                    int *np_out) {
+  if (!m || nr < 0) { jur_set_error("formod_host: bad arguments"); return JUR_EINVAL; }
+  if (nr == 0) return JUR_OK;
+  HIPCHK(hipSetDevice(m->device));
+  int const nd = m->view.nd;
+  if (nr > m->io_cap) {
+    if (m->d_io) (void)hipFree(m->d_io);
+    if (m->d_io_np) (void)hipFree(m->d_io_np);
+    m->d_io = NULL; m->d_io_np = NULL; m->io_cap = 0;
+    HIPCHK(hipMalloc((void **)&m->d_io, sizeof(double) * (size_t)nr * (10 + 2 * (size_t)nd)));
+    HIPCHK(hipMalloc((void **)&m->d_io_np, sizeof(int) * (size_t)nr));
+    m->io_cap = nr;
+  }
+  double *d_geom = m->d_io, *d_tp = d_geom + 7 * (size_t)nr, *d_rad = d_tp + 3 * (size_t)nr,
+         *d_tau = d_rad + (size_t)nr * nd;
+  hipStream_t s = m->stream;
+  for (int k = 0; k < 7; k++)
+    HIPCHK(hipMemcpyAsync(d_geom + (size_t)k * nr, geom[k], sizeof(double) * nr, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_rad, rad, sizeof(double) * (size_t)nr * nd, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(m->d_status, 0, sizeof(int), s));
+  int rc = jur_formod_device(m, nr, d_geom, d_rad, d_tau, d_tp, m->d_io_np, m->d_status, s);
+  if (rc) return rc;
+  int status = 0;
+  for (int k = 0; k < 3; k++)
+    HIPCHK(hipMemcpyAsync(tp[k], d_tp + (size_t)k * nr, sizeof(double) * nr, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(rad, d_rad, sizeof(double) * (size_t)nr * nd, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(tau, d_tau, sizeof(double) * (size_t)nr * nd, hipMemcpyDeviceToHost, s));
+  if (np_out) HIPCHK(hipMemcpyAsync(np_out, m->d_io_np, sizeof(int) * nr, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (status & 1) { jur_set_error("Too many LOS points! (a ray needs %d or more)", JUR_NLOS); return JUR_ENLOS; }
+  return JUR_OK;
+}
+
+/* ---- drop-in entry points ------------------------------------------------------ */
+#define DIE(...)                                                                 \
+  do {                                                                           \
+    printf("\nError (%s, %s, l%d): ", __FILE__, __func__, __LINE__);             \
+    printf(__VA_ARGS__);                                                         \
+    printf("\n\n");                                                              \
+    fflush(stdout);                                                              \
+    exit(EXIT_FAILURE);                                                          \
+  } while (0)
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static jur_model_t *g_model = NULL;   /* process-lifetime cache, like upstream's static tbl */
+
+static jur_model_t *global_model(ctl_t const *ctl) {
+  if (!g_model) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+      DIE("no GPU found: this library has no CPU path (USEGPU = %d)", ctl->useGPU);
+    int device = ctl->MPIlocalrank;               /* GPUdrivers.cu:344 */
+    if (device < 0 || device >= ndev) device = 0;
+    printf("Initialize emissivity tables and source function (MI355X path, device %d)...\n", device);
+    if (jur_model_create_from_files(&g_model, ctl, device) != JUR_OK) DIE("%s", jur_last_error());
+  } else {
+    /* upstream ignores later changes of nu/emitter but re-reads the rest of ctl on
+     * every call (GPUdrivers.cu:355); mirror the run-time switches */
+    jur_view_t *v = &g_model->view;
+    if (ctl->ng != v->ng || ctl->nd != v->nd) DIE("ng/nd changed after the tables were initialised");
+    memcpy(g_model->ctl, ctl, sizeof(ctl_t));
+    v->refrac = ctl->refrac; v->write_bbt = ctl->write_bbt; v->rayds = ctl->rayds; v->raydz = ctl->raydz;
+    v->fourbit = ((1 == ctl->ctm_co2) && (v->ig_co2 >= 0)) * 8 + ((1 == ctl->ctm_h2o) && (v->ig_h2o >= 0)) * 4
+               + (1 == ctl->ctm_n2) * 2 + (1 == ctl->ctm_o2) * 1;
+  }
+  return g_model;
+}
+
+static void formod_range(ctl_t const *ctl, atm_t *atm, obs_t *obs, int r0, int nr) {
+  if (ctl->checkmode) { printf("# %s: no operation in checkmode\n", __func__); return; }
+  if (!obs || !atm) DIE("null argument");
+  if (r0 < 0 || nr < 0 || r0 + nr > JUR_NR) DIE("ray range outside the package (max %d rays)", JUR_NR);
+  if (nr == 0) return;
+  pthread_mutex_lock(&g_lock);                    /* upstream: omp critical + lanes */
+  jur_model_t *m = global_model(ctl);
+  if (jur_model_set_atm(m, atm) != JUR_OK) DIE("%s", jur_last_error());
+  int const nd = ctl->nd;
+  double *buf = (double *)malloc(sizeof(double) * (size_t)nr * 2 * nd);
+  double *rad = buf, *tau = buf + (size_t)nr * nd;
+  for (int i = 0; i < nr; i++)
+    for (int id = 0; id < nd; id++) rad[(size_t)i * nd + id] = obs->rad[r0 + i][id];
+  double const *geom[7] = {obs->time + r0, obs->obsz + r0, obs->obslon + r0, obs->obslat + r0,
+                           obs->vpz + r0, obs->vplon + r0, obs->vplat + r0};
+  double *tp[3] = {obs->tpz + r0, obs->tplon + r0, obs->tplat + r0};
+  int const rc = jur_formod_host(m, nr, geom, rad, tau, tp, NULL);
+  if (rc == JUR_ENLOS) DIE("Too many LOS points!");
+  if (rc != JUR_OK) DIE("%s", jur_last_error());
+  for (int i = 0; i < nr; i++) {
+    for (int id = 0; id < nd; id++) {
+      obs->rad[r0 + i][id] = rad[(size_t)i * nd + id];
+      obs->tau[r0 + i][id] = tau[(size_t)i * nd + id];
+    }
+    for (int id = nd; id < JUR_ND; id++) {          /* upstream clears all ND channels, CPUdrivers.c:58-60 */
+      obs->rad[r0 + i][id] = 0.0;
+      obs->tau[r0 + i][id] = 1.0;
+    }
+  }
+  free(buf);
+  pthread_mutex_unlock(&g_lock);
+}
+
+void formod_GPU(ctl_t const *ctl, atm_t *atm, obs_t *obs) { formod_range(ctl, atm, obs, 0, obs ? obs->nr : 0); }
+
+void formod(ctl_t const *ctl, atm_t *atm, obs_t *obs) {
+  if (ctl->checkmode)
+    printf("# %s: %d max %d rays , %d of max %d gases, %d of max %d channels\n", __func__, obs->nr, JUR_NR, ctl->ng,
+           JUR_NG, ctl->nd, JUR_ND);
+  /* USEGPU = 0 ("never") has no meaning here: every path is the GPU path. */
+  formod_GPU(ctl, atm, obs);
+}
+
+void formod_pencil(ctl_t const *ctl, atm_t *atm, obs_t *obs, int const ir) { formod_range(ctl, atm, obs, ir, 1); }

@@ -1,0 +1,351 @@
+/* jur_tables.c -- host side of the emissivity/source-function tables.
+ *
+ * Builds, per (gas, channel), a ragged p -> T -> (u, eps) hierarchy from the
+ * reference's ASCII table rows and flattens it to the CSR-like arrays the
+ * kernels read.  Row acceptance reproduces the behaviour of the reference
+ * loader (src/jurassic.c:346-395): a new pressure / temperature block starts
+ * when the value changes; a row extends a curve only if both eps and u grow
+ * (or it opens the curve), otherwise it overwrites the curve's last entry;
+ * rows beyond TBLNU entries are dropped.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "jur_internal.h"
+
+/* ---- error text ----------------------------------------------------------- */
+static __thread char g_err[512];
+
+void jur_set_error(char const *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+char const *jur_last_error(void) { return g_err; }
+
+void jur_abi_sizes(size_t out[5]) {
+  out[0] = sizeof(ctl_t); out[1] = sizeof(atm_t); out[2] = sizeof(obs_t);
+  out[3] = JUR_ND; out[4] = JUR_NG;
+}
+
+/* ---- continuum coefficient data ------------------------------------------- */
+#ifndef CTM_BLOB_PATH
+#error "compile with -DCTM_BLOB_PATH"
+#endif
+__asm__(".section .rodata\n"
+        ".balign 16\n"
+        ".global jur_ctm_blob\n"
+        ".hidden jur_ctm_blob\n"
+        "jur_ctm_blob:\n"
+        ".incbin \"" CTM_BLOB_PATH "\"\n"
+        ".previous\n");
+
+enum { B_CO2_296 = 0, B_CO2_260 = 2001, B_CO2_230 = 4002, B_H2O_296 = 6003, B_H2O_260 = 8004,
+       B_H2O_FRN = 10005, B_N2_B = 12006, B_N2_BETA = 12104, B_O2_B = 12202, B_O2_BETA = 12292 };
+
+static double grid_lerp(int base, int iw, double ew, double dw) {
+  return ew * jur_ctm_blob[base + iw - 1] + dw * jur_ctm_blob[base + iw];
+}
+
+/* Channel-only part of the four continua.  The expressions keep the operand
+ * order of jr_common.h:315-390 so the products formed here are the same
+ * doubles the reference forms per call. */
+void jur_chan_setup(jur_chan_t *ch, double nu, int window) {
+  memset(ch, 0, sizeof *ch);
+  ch->nu = nu;
+  ch->window = window;
+  if (!(nu < 0 || nu >= 4000)) {                        /* CO2, 2 cm^-1 grid */
+    double const xw = nu * 0.5 + 1;
+    int const iw = (int)xw;
+    double const dw = xw - iw, ew = 1 - dw;
+    ch->co2_on = 1;
+    ch->co2_cw296 = grid_lerp(B_CO2_296, iw, ew, dw);
+    ch->co2_cw260 = grid_lerp(B_CO2_260, iw, ew, dw);
+    ch->co2_cw230 = grid_lerp(B_CO2_230, iw, ew, dw);
+  }
+  if (!(nu < 0 || nu >= 20000)) {                       /* H2O, 10 cm^-1 grid */
+    double const xw = nu / 10 + 1;
+    int const iw = (int)xw;
+    double const dw = xw - iw, ew = 1 - dw;
+    double const cw296 = grid_lerp(B_H2O_296, iw, ew, dw);
+    double const cw260 = grid_lerp(B_H2O_260, iw, ew, dw);
+    double const cwfrn = grid_lerp(B_H2O_FRN, iw, ew, dw);
+    double sfac = 1.;
+    if ((nu > 820.) && (nu < 960.)) {                   /* single-precision correction, jr_common.h:345-351 */
+      static char const xfcrev[16] = {3, 9, 15, 23, 29, 33, 37, 39, 40, 46, 36, 27, 10, 2, 0, 0};
+      float const xx = nu * 0.1 - 82;
+      int const ix = (int)xx;
+      float const dx = xx - ix;
+      sfac += .001 * ((1 - dx) * xfcrev[ix] + dx * xfcrev[ix + 1]);
+    }
+    double const vf1 = nu - 370.;
+    double const vf2 = vf1 * vf1;
+    double const vf6 = vf2 * vf2 * vf2;
+    double const fscal = 36100. / (vf2 + vf6 * 1e-8 + 36100.) * -.25 + 1.;
+    ch->h2o_on = 1;
+    ch->h2o_sc = sfac * cw296;
+    ch->h2o_ratio = cw260 / cw296;
+    ch->h2o_ctwfrn = cwfrn * fscal;
+  }
+  if (!(nu < 2120 || nu > 2605)) {                      /* N2, 5 cm^-1 grid, 98 entries */
+    double const xnu = nu * 0.2 - 424;
+    int const idx = (int)xnu;
+    int const idx1 = (idx + 1 < 98) ? idx + 1 : 97;     /* upstream reads one past the end at weight 0 */
+    double const a1 = xnu - idx, a0 = 1 - a1;
+    ch->n2_on = 1;
+    ch->n2_b = a0 * jur_ctm_blob[B_N2_B + idx] + a1 * jur_ctm_blob[B_N2_B + idx1];
+    ch->n2_beta = a0 * jur_ctm_blob[B_N2_BETA + idx] + a1 * jur_ctm_blob[B_N2_BETA + idx1];
+  }
+  if (!(nu < 1360 || nu > 1805)) {                      /* O2, 5 cm^-1 grid, 90 entries */
+    double const xnu = nu * 0.2 - 272;
+    int const idx = (int)xnu;
+    int const idx1 = (idx + 1 < 90) ? idx + 1 : 89;
+    double const a1 = xnu - idx, a0 = 1 - a1;
+    ch->o2_on = 1;
+    ch->o2_b = a0 * jur_ctm_blob[B_O2_B + idx] + a1 * jur_ctm_blob[B_O2_B + idx1];
+    ch->o2_beta = a0 * jur_ctm_blob[B_O2_BETA + idx] + a1 * jur_ctm_blob[B_O2_BETA + idx1];
+  }
+}
+
+/* ---- table builder --------------------------------------------------------- */
+jur_tables_t *jur_tables_new(int ng, int nd) {
+  if (ng < 0 || nd < 1) { jur_set_error("jur_tables_new: bad dimensions ng=%d nd=%d", ng, nd); return NULL; }
+  jur_tables_t *tb = (jur_tables_t *)calloc(1, sizeof *tb);
+  if (!tb) return NULL;
+  tb->ng = ng;
+  tb->nd = nd;
+  tb->pair = (jur_pair_t *)calloc((size_t)(ng > 0 ? ng : 1) * nd, sizeof(jur_pair_t));
+  tb->sr = (double *)calloc((size_t)nd * JUR_TBLNS, sizeof(double));
+  tb->have_sr = (char *)calloc(nd, 1);
+  if (!tb->pair || !tb->sr || !tb->have_sr) { jur_tables_free(tb); return NULL; }
+  return tb;
+}
+
+static void pair_clear(jur_pair_t *pr) {
+  for (int ip = 0; ip < pr->np; ip++)
+    for (int it = 0; it < JUR_TBLNT; it++) { free(pr->lv[ip].cv[it].u); free(pr->lv[ip].cv[it].eps); }
+  free(pr->lv);
+  pr->lv = NULL;
+  pr->np = 0;
+}
+
+void jur_tables_free(jur_tables_t *tb) {
+  if (!tb) return;
+  if (tb->pair)
+    for (long i = 0; i < (long)tb->ng * tb->nd; i++) pair_clear(&tb->pair[i]);
+  free(tb->pair); free(tb->sr); free(tb->have_sr); free(tb);
+}
+
+typedef struct {
+  double press_old, temp_old, eps_old, u_old;
+  int ip, it, iu, cap_lv;
+} feeder_t;
+
+static int feed_one(jur_tables_t *tb, jur_pair_t *pr, feeder_t *f, double press, double temp, double u, double eps) {
+  if (press != f->press_old) {
+    f->press_old = press;
+    if (++f->ip >= JUR_TBLNP) { jur_set_error("too many pressure levels (max %d)", JUR_TBLNP); return JUR_EINVAL; }
+    if (f->ip >= f->cap_lv) {
+      int const cap = f->cap_lv ? 2 * f->cap_lv : 8;
+      jur_level_t *lv = (jur_level_t *)realloc(pr->lv, sizeof(jur_level_t) * cap);
+      if (!lv) return JUR_ENOMEM;
+      memset(lv + f->cap_lv, 0, sizeof(jur_level_t) * (cap - f->cap_lv));
+      pr->lv = lv;
+      f->cap_lv = cap;
+    }
+    pr->np = f->ip + 1;
+    f->it = -1;
+  }
+  jur_level_t *lv = &pr->lv[f->ip];
+  if (temp != f->temp_old) {
+    f->temp_old = temp;
+    if (++f->it >= JUR_TBLNT) { jur_set_error("too many temperatures (max %d)", JUR_TBLNT); return JUR_EINVAL; }
+    lv->nt = f->it + 1;
+    f->iu = -1;
+  }
+  if (f->it < 0) {
+    /* upstream would index [-1] here: a pressure block whose first temperature repeats the
+     * previous block's last one */
+    jur_set_error("table block at p=%g repeats the previous temperature %g", press, temp);
+    return JUR_EINVAL;
+  }
+  jur_curve_t *cv = &lv->cv[f->it];
+  if ((eps > f->eps_old && u > f->u_old) || f->iu < 0) {
+    f->eps_old = eps;
+    f->u_old = u;
+    if (++f->iu >= JUR_TBLNU) {
+      tb->ignored_rows++;
+      f->iu--;
+      return JUR_OK;
+    }
+  }
+  if (f->iu >= cv->cap) {
+    int const cap = cv->cap ? 2 * cv->cap : 64;
+    float *nu_ = (float *)realloc(cv->u, sizeof(float) * cap);
+    float *ne = (float *)realloc(cv->eps, sizeof(float) * cap);
+    if (nu_) cv->u = nu_;
+    if (ne) cv->eps = ne;
+    if (!nu_ || !ne) return JUR_ENOMEM;
+    cv->cap = cap;
+  }
+  lv->p = press;
+  cv->t = temp;
+  cv->u[f->iu] = (float)u;
+  cv->eps[f->iu] = (float)eps;
+  cv->nu = f->iu + 1;
+  return JUR_OK;
+}
+
+static void feeder_init(feeder_t *f) {
+  f->press_old = f->temp_old = f->eps_old = f->u_old = -999;
+  f->ip = f->it = f->iu = -1;
+  f->cap_lv = 0;
+}
+
+int jur_tables_feed_rows(jur_tables_t *tb, int ig, int id, long nrows, double const *p, double const *t,
+                         double const *u, double const *eps) {
+  if (!tb || ig < 0 || ig >= tb->ng || id < 0 || id >= tb->nd) { jur_set_error("feed_rows: index out of range"); return JUR_EINVAL; }
+  jur_pair_t *pr = &tb->pair[(size_t)ig * tb->nd + id];
+  pair_clear(pr);
+  feeder_t f;
+  feeder_init(&f);
+  for (long i = 0; i < nrows; i++) {
+    int const rc = feed_one(tb, pr, &f, p[i], t[i], u[i], eps[i]);
+    if (rc) return rc;
+  }
+  return JUR_OK;
+}
+
+int jur_tables_read_ascii(jur_tables_t *tb, ctl_t const *ctl) {
+  if (!tb || tb->ng < ctl->ng || tb->nd < ctl->nd) { jur_set_error("read_ascii: tables smaller than ctl"); return JUR_EINVAL; }
+  int found = 0;
+  char *line = (char *)malloc(JUR_LEN);
+  for (int ig = 0; ig < ctl->ng; ig++)
+    for (int id = 0; id < ctl->nd; id++) {
+      char filename[2 * JUR_LEN + 64];
+      snprintf(filename, sizeof filename, "%s_%.4f_%s.tab", ctl->tblbase, ctl->nu[id], ctl->emitter[ig]);
+      FILE *in = fopen(filename, "r");
+      if (!in) continue;                                /* transparent gas for this channel */
+      found++;
+      jur_pair_t *pr = &tb->pair[(size_t)ig * tb->nd + id];
+      pair_clear(pr);
+      feeder_t f;
+      feeder_init(&f);
+      while (fgets(line, JUR_LEN, in)) {
+        double eps = 0, press = 0, temp = 0, u = 0;
+        if (sscanf(line, "%lg %lg %lg %lg", &press, &temp, &u, &eps) != 4) continue;
+        int const rc = feed_one(tb, pr, &f, press, temp, u, eps);
+        if (rc) { fclose(in); free(line); return rc; }
+      }
+      fclose(in);
+    }
+  free(line);
+  if (tb->ignored_rows > 0)
+    fprintf(stderr, "Warning! %ld table entries ignored (more than %d column densities per curve)\n",
+            tb->ignored_rows, JUR_TBLNU);
+  return found;
+}
+
+/* Planck function as the reference evaluates it: C1 nu^3 / (exp(C2 nu / T) - 1)
+ * (jurassic.c:860; GSL's expm1 is exp(x)-1 for |x| >= ln 2). */
+static double planck(double t, double nu) {
+  double const x = JUR_C2 * nu / t;
+  double const em1 = (fabs(x) < M_LN2) ? expm1(x) : exp(x) - 1;
+  return JUR_C1 * (nu * nu * nu) / em1;
+}
+
+int jur_tables_set_filter(jur_tables_t *tb, int id, int n, double const *nu, double const *f) {
+  if (!tb || id < 0 || id >= tb->nd || n < 1) { jur_set_error("set_filter: bad arguments"); return JUR_EINVAL; }
+  double *sr = tb->sr + (size_t)id * JUR_TBLNS;
+  for (int it = 0; it < JUR_TBLNS; it++) {
+    double const st = 100 + ((double)it - 0.0) * (400 - 100) / ((JUR_TBLNS - 1.0) - 0.0);
+    double fsum = 0, fpsum = 0;
+    for (int i = 0; i < n; i++) {
+      fsum += f[i];
+      fpsum += f[i] * planck(st, nu[i]);
+    }
+    sr[it] = fpsum / fsum;
+  }
+  tb->have_sr[id] = 1;
+  return JUR_OK;
+}
+
+int jur_tables_read_filters(jur_tables_t *tb, ctl_t const *ctl) {
+  double *nu = (double *)malloc(sizeof(double) * JUR_NSHAPE), *f = (double *)malloc(sizeof(double) * JUR_NSHAPE);
+  char *line = (char *)malloc(JUR_LEN);
+  int rc = JUR_OK;
+  for (int id = 0; id < ctl->nd && rc == JUR_OK; id++) {
+    char filename[JUR_LEN + 64];
+    snprintf(filename, sizeof filename, "%s_%.4f.filt", ctl->tblbase, ctl->nu[id]);
+    FILE *in = fopen(filename, "r");
+    if (!in) { jur_set_error("cannot open filter function %s", filename); rc = JUR_EIO; break; }
+    int n = 0;
+    while (fgets(line, JUR_LEN, in))
+      if (n < JUR_NSHAPE && sscanf(line, "%lg %lg", &nu[n], &f[n]) == 2) n++;
+    fclose(in);
+    if (n < 1) { jur_set_error("no data in filter function %s", filename); rc = JUR_EIO; break; }
+    rc = jur_tables_set_filter(tb, id, n, nu, f);
+  }
+  free(nu); free(f); free(line);
+  return rc;
+}
+
+long jur_tables_entries(jur_tables_t const *tb) {
+  long n = 0;
+  for (long i = 0; i < (long)tb->ng * tb->nd; i++)
+    for (int ip = 0; ip < tb->pair[i].np; ip++)
+      for (int it = 0; it < tb->pair[i].lv[ip].nt; it++) n += tb->pair[i].lv[ip].cv[it].nu;
+  return n;
+}
+
+/* ---- flatten --------------------------------------------------------------- */
+int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
+  memset(out, 0, sizeof *out);
+  long const npair = (long)tb->ng * tb->nd;
+  long nlevel = 0, ncurve = 0, nentry = 0;
+  for (long i = 0; i < npair; i++) {
+    nlevel += tb->pair[i].np;
+    for (int ip = 0; ip < tb->pair[i].np; ip++) {
+      ncurve += tb->pair[i].lv[ip].nt;
+      for (int it = 0; it < tb->pair[i].lv[ip].nt; it++) nentry += tb->pair[i].lv[ip].cv[it].nu;
+    }
+  }
+  if (nentry >= 0x7fffffffL) { jur_set_error("tables too large for 32-bit offsets (%ld entries)", nentry); return JUR_EINVAL; }
+  out->nlevel = nlevel; out->ncurve = ncurve; out->nentry = nentry;
+  out->pair = (jur_int2 *)calloc(npair > 0 ? npair : 1, sizeof(jur_int2));
+  out->plev = (double *)calloc(nlevel + 1, sizeof(double));
+  out->lvl = (jur_int2 *)calloc(nlevel + 1, sizeof(jur_int2));
+  out->tval = (double *)calloc(ncurve + 1, sizeof(double));
+  out->crv = (jur_int2 *)calloc(ncurve + 1, sizeof(jur_int2));
+  out->ue = (jur_ue_t *)calloc(nentry + 2, sizeof(jur_ue_t));
+  if (!out->pair || !out->plev || !out->lvl || !out->tval || !out->crv || !out->ue) { jur_flat_free(out); return JUR_ENOMEM; }
+  long L = 0, K = 0, E = 0;
+  for (long i = 0; i < npair; i++) {
+    jur_pair_t const *pr = &tb->pair[i];
+    out->pair[i].a = pr->np;
+    out->pair[i].b = (int)L;
+    for (int ip = 0; ip < pr->np; ip++, L++) {
+      out->plev[L] = pr->lv[ip].p;
+      out->lvl[L].a = pr->lv[ip].nt;
+      out->lvl[L].b = (int)K;
+      for (int it = 0; it < pr->lv[ip].nt; it++, K++) {
+        jur_curve_t const *cv = &pr->lv[ip].cv[it];
+        out->tval[K] = cv->t;
+        out->crv[K].a = cv->nu;
+        out->crv[K].b = (int)E;
+        for (int iu = 0; iu < cv->nu; iu++, E++) { out->ue[E].u = cv->u[iu]; out->ue[E].eps = cv->eps[iu]; }
+      }
+    }
+  }
+  return JUR_OK;
+}
+
+void jur_flat_free(jur_flat_t *f) {
+  free(f->pair); free(f->plev); free(f->lvl); free(f->tval); free(f->crv); free(f->ue);
+  memset(f, 0, sizeof *f);
+}

@@ -1,0 +1,75 @@
+"""ctypes mirrors of the structs that cross the formod() boundary.
+
+Field order and sizes follow include/jurassic_abi.h, which restates the
+reference's src/jurassic.h:215-226 (atm_t), :229-347 (ctl_t), :371-385 (obs_t).
+"""
+import ctypes as C
+
+ND, NG, NP, NR, NW, LEN, NLOS = 100, 30, 9600, 1088, 1, 5000, 400
+TBLNP, TBLNT, TBLNU, TBLNS = 40, 30, 304, 1201
+
+d = C.c_double
+i = C.c_int
+
+
+class atm_t(C.Structure):
+    _fields_ = [("time", d * NP), ("z", d * NP), ("lon", d * NP), ("lat", d * NP),
+                ("p", d * NP), ("t", d * NP), ("q", (d * NP) * NG), ("k", (d * NP) * NW),
+                ("np", i), ("init", i)]
+
+
+class ctl_t(C.Structure):
+    _fields_ = [("ng", i), ("emitter", (C.c_char * LEN) * NG), ("nd", i), ("nw", i),
+                ("nu", d * ND), ("window", i * ND), ("tblbase", C.c_char * LEN),
+                ("hydz", d), ("ctm_co2", i), ("ctm_h2o", i), ("ctm_n2", i), ("ctm_o2", i),
+                ("ip", i), ("cz", d), ("cx", d), ("refrac", i), ("rayds", d), ("raydz", d),
+                ("fov", C.c_char * LEN),
+                ("retp_zmin", d), ("retp_zmax", d), ("rett_zmin", d), ("rett_zmax", d),
+                ("retq_zmin", d * NG), ("retq_zmax", d * NG), ("retk_zmin", d * NW), ("retk_zmax", d * NW),
+                ("write_bbt", i), ("write_matrix", i), ("formod", i),
+                ("rfmbin", C.c_char * LEN), ("rfmhit", C.c_char * LEN), ("rfmxsc", (C.c_char * LEN) * NG),
+                ("useGPU", i), ("checkmode", i), ("MPIglobrank", i), ("MPIlocalrank", i),
+                ("read_binary", i), ("write_binary", i), ("gpu_nbytes_shared_memory", i)]
+
+
+class obs_t(C.Structure):
+    _fields_ = [("time", d * NR), ("obsz", d * NR), ("obslon", d * NR), ("obslat", d * NR),
+                ("vpz", d * NR), ("vplon", d * NR), ("vplat", d * NR),
+                ("tpz", d * NR), ("tplon", d * NR), ("tplat", d * NR),
+                ("tau", (d * ND) * NR), ("rad", (d * ND) * NR), ("nr", i)]
+
+
+assert C.sizeof(ctl_t) == 321856 and C.sizeof(atm_t) == 2841608 and C.sizeof(obs_t) == 1827848
+
+
+def make_ctl(emitters, nu, tblbase="-", **kw):
+    """Control block with read_ctl's defaults (reference src/jurassic.c:920-1021),
+    including the automatic continuum switch-off at :954-968."""
+    ctl = ctl_t()
+    ctl.ng = len(emitters)
+    for g, name in enumerate(emitters):
+        ctl.emitter[g].value = name.encode()
+    ctl.nd = len(nu)
+    ctl.nw = 1
+    for k, v in enumerate(nu):
+        ctl.nu[k] = float(v)
+        ctl.window[k] = 0
+    ctl.tblbase = tblbase.encode()
+    ctl.hydz = -999.0
+    ctl.ctm_co2 = ctl.ctm_h2o = ctl.ctm_n2 = ctl.ctm_o2 = 1
+    ctl.ip = 1
+    ctl.refrac = 1
+    ctl.rayds = 10.0
+    ctl.raydz = 0.5
+    ctl.fov = b"-"
+    ctl.formod = 2
+    ctl.read_binary = -1
+    ctl.write_binary = 1
+    for k, v in kw.items():
+        setattr(ctl, k, v)
+    if "ctm_auto" not in kw:
+        if not any(x < 4000 for x in nu): ctl.ctm_co2 = 0
+        if not any(x < 20000 for x in nu): ctl.ctm_h2o = 0
+        if not any(2120 <= x <= 2605 for x in nu): ctl.ctm_n2 = 0
+        if not any(1360 <= x <= 1805 for x in nu): ctl.ctm_o2 = 0
+    return ctl

@@ -1,0 +1,164 @@
+"""ctypes binding of libjurassic_hip.so (include/jurassic_hip.h).
+
+The library is the product; this module only marshals arguments.  It raises if
+the shared object is missing -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import numpy as np
+from . import abi
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(PKG, "libjurassic_hip.so")
+_lib = None
+dp = C.POINTER(C.c_double)
+
+
+class JurassicError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise JurassicError(f"{SO} not built: run `make -C jurassic-gpu_amd/csrc` "
+                                "or __graft_entry__.build(); no CPU fallback exists")
+        L = C.CDLL(SO)
+        L.jur_last_error.restype = C.c_char_p
+        L.jur_tables_new.restype = C.c_void_p
+        L.jur_tables_new.argtypes = [C.c_int, C.c_int]
+        L.jur_tables_free.argtypes = [C.c_void_p]
+        L.jur_tables_feed_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, dp, dp, dp, dp]
+        L.jur_tables_read_ascii.argtypes = [C.c_void_p, C.c_void_p]
+        L.jur_tables_set_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp]
+        L.jur_tables_read_filters.argtypes = [C.c_void_p, C.c_void_p]
+        L.jur_tables_entries.restype = C.c_long
+        L.jur_tables_entries.argtypes = [C.c_void_p]
+        L.jur_model_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int]
+        L.jur_model_create_from_files.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+        L.jur_model_destroy.argtypes = [C.c_void_p]
+        L.jur_model_set_atm.argtypes = [C.c_void_p, C.c_void_p]
+        L.jur_formod_host.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
+        L.jur_formod_device.argtypes = [C.c_void_p, C.c_long] + [C.c_void_p] * 7
+        L.jur_model_workspace_bytes.restype = C.c_long
+        L.jur_model_workspace_bytes.argtypes = [C.c_void_p]
+        L.jur_model_chunk_rays.argtypes = [C.c_void_p]
+        L.jur_model_set_chunk_rays.argtypes = [C.c_void_p, C.c_int]
+        L.jur_model_enable_timing.argtypes = [C.c_void_p, C.c_int]
+        L.jur_model_last_kernel_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
+        L.jur_abi_sizes.argtypes = [C.POINTER(C.c_size_t)]
+        for name in ("formod", "formod_GPU"):
+            getattr(L, name).argtypes = [C.c_void_p] * 3
+            getattr(L, name).restype = None
+        L.formod_pencil.argtypes = [C.c_void_p] * 3 + [C.c_int]
+        L.formod_pencil.restype = None
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc < 0:
+        raise JurassicError(f"jurassic_hip error {rc}: {lib().jur_last_error().decode()}")
+    return rc
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+class Tables:
+    def __init__(self, ng, nd):
+        self.h = lib().jur_tables_new(ng, nd)
+        if not self.h:
+            raise JurassicError(lib().jur_last_error().decode())
+        self.ng, self.nd = ng, nd
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().jur_tables_free(self.h)
+            self.h = None
+
+    def feed_rows(self, ig, id_, rows):
+        r = np.ascontiguousarray(rows, dtype=np.float64)
+        cols = [np.ascontiguousarray(r[:, k]) for k in range(4)]
+        _chk(lib().jur_tables_feed_rows(self.h, ig, id_, len(r), *[_p(c) for c in cols]))
+
+    def read_ascii(self, ctl):
+        return _chk(lib().jur_tables_read_ascii(self.h, C.byref(ctl)))
+
+    def set_filter(self, id_, nu, f):
+        nu = np.ascontiguousarray(nu, dtype=np.float64)
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        _chk(lib().jur_tables_set_filter(self.h, id_, len(nu), _p(nu), _p(f)))
+
+    def read_filters(self, ctl):
+        _chk(lib().jur_tables_read_filters(self.h, C.byref(ctl)))
+
+    def entries(self):
+        return lib().jur_tables_entries(self.h)
+
+
+class Model:
+    """Control block + tables resident on one GPU."""
+
+    def __init__(self, ctl, tables=None, device=0):
+        h = C.c_void_p()
+        if tables is None:
+            _chk(lib().jur_model_create_from_files(C.byref(h), C.byref(ctl), device))
+        else:
+            _chk(lib().jur_model_create(C.byref(h), C.byref(ctl), tables.h, device))
+        self.h = h
+        self.nd = ctl.nd
+        self.ng = ctl.ng
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().jur_model_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_atm(self, atm):
+        _chk(lib().jur_model_set_atm(self.h, C.byref(atm)))
+
+    def set_chunk_rays(self, n):
+        _chk(lib().jur_model_set_chunk_rays(self.h, n))
+
+    def formod_host(self, geom, rad_in=None):
+        """geom: (nr, 7).  -> dict(rad, tau, tp (nr,3), np)."""
+        g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
+        nr, nd = g.shape[1], self.nd
+        rad = np.zeros((nr, nd)) if rad_in is None else np.ascontiguousarray(rad_in, dtype=np.float64).copy()
+        tau = np.zeros((nr, nd))
+        tp = np.zeros((3, nr))
+        npts = np.zeros(nr, dtype=np.int32)
+        garr = (dp * 7)(*[_p(g[k]) for k in range(7)])
+        tarr = (dp * 3)(*[_p(tp[k]) for k in range(3)])
+        _chk(lib().jur_formod_host(self.h, nr, garr, _p(rad), _p(tau), tarr, npts.ctypes.data_as(C.POINTER(C.c_int))))
+        return dict(rad=rad, tau=tau, tp=np.ascontiguousarray(tp.T), np=npts)
+
+    def formod_device(self, nr, d_geom, d_rad, d_tau, d_tp, d_np=0, d_status=0, stream=0):
+        """All arguments are raw device addresses (ints), e.g. torch_tensor.data_ptr()."""
+        _chk(lib().jur_formod_device(self.h, nr, d_geom, d_rad, d_tau, d_tp, d_np, d_status, stream))
+
+    def enable_timing(self, on=True):
+        _chk(lib().jur_model_enable_timing(self.h, int(on)))
+
+    def kernel_ms(self):
+        ms = (C.c_double * 2)()
+        n = (C.c_long * 2)()
+        _chk(lib().jur_model_last_kernel_ms(self.h, ms, n))
+        return dict(trace_ms=ms[0], integrate_ms=ms[1], trace_launches=n[0], integrate_launches=n[1])
+
+    def workspace_bytes(self):
+        return lib().jur_model_workspace_bytes(self.h)
+
+
+def formod(ctl, atm, obs):
+    """Drop-in entry (reference CPUdrivers.c:179): tables from ctl.tblbase files."""
+    lib().formod(C.byref(ctl), C.byref(atm), C.byref(obs))
+
+
+def formod_pencil(ctl, atm, obs, ir):
+    lib().formod_pencil(C.byref(ctl), C.byref(atm), C.byref(obs), ir)

@@ -1,0 +1,123 @@
+"""Seeded synthetic inputs: emissivity tables, filter functions, observation
+geometries and stacked atmosphere profiles.
+
+The geometry formulas restate the reference's generators: limb tangent-height
+scan src/limb.c:49-59, nadir latitude sweep src/nadir.c:51-58; the profile
+perturbation follows src/climatology.c:65-78 (p*(1+dp), T+dT per profile).
+"""
+import numpy as np
+from . import abi
+
+RE = 6367.421
+
+# absorption strength per molecule/cm^2 at 1000 hPa, 250 K, by emitter
+K0 = {"CO2": 5e-23, "H2O": 2e-22, "O3": 5e-21, "F11": 1e-17, "CCL4": 2e-17}
+
+
+def table_rows(emitter, nu, id_=0, nlev=33, ntemp=10, descending=False, umax_eps=0.99999, ratio=1.122):
+    """Rows (p, T, u, eps) of one synthetic table in file order.
+
+    p: nlev levels 0.016..1000 hPa (log-spaced, ascending unless `descending`);
+    T: ntemp values per level, 15 K apart, the axis shifted by 2 K*(level%3) so
+       neighbouring levels do not share their temperature brackets;
+    u: geometric grid with the given ratio from eps~1e-6 to eps>umax_eps;
+    eps = 1 - exp(-(k u)^0.7), k = k0 sqrt(p/1000) 250/T (1+0.3 id_) (nu/800)^2."""
+    k0 = K0.get(emitter.upper(), 1e-21) * (1 + 0.3 * id_) * (nu / 800.0) ** 2
+    plev = np.exp(np.linspace(np.log(0.016), np.log(1000.0), nlev))
+    if descending:
+        plev = plev[::-1]
+    rows = []
+    for il, p in enumerate(plev):
+        for t in 180.0 + 2.0 * (il % 3) + 15.0 * np.arange(ntemp):
+            k = k0 * np.sqrt(p / 1000.0) * 250.0 / t
+            u = (1e-6 ** (1 / 0.7)) / k
+            while True:
+                eps = 1.0 - np.exp(-(k * u) ** 0.7)
+                rows.append((p, t, u, eps))
+                if eps > umax_eps:
+                    break
+                u *= ratio
+    return np.array(rows)
+
+
+def write_table_file(path, rows):
+    with open(path, "w") as fh:
+        fh.write("# $1 = pressure [hPa]\n# $2 = temperature [K]\n"
+                 "# $3 = column density [molecules/cm^2]\n# $4 = emissivity\n\n")
+        for p, t, u, e in rows:
+            fh.write("%.9g %.9g %.9g %.9g\n" % (p, t, u, e))
+
+
+def parse_table_file(path):
+    out = []
+    with open(path) as fh:
+        for line in fh:
+            tok = line.split()
+            if len(tok) >= 4:
+                try:
+                    out.append([float(x) for x in tok[:4]])
+                except ValueError:
+                    pass
+    return np.array(out)
+
+
+def boxcar_filter(nu, halfwidth=0.5, n=21):
+    x = np.linspace(nu - halfwidth, nu + halfwidth, n)
+    f = np.ones(n)
+    f[0] = f[-1] = 0.0
+    return x, f
+
+
+def write_filter_file(path, x, f):
+    with open(path, "w") as fh:
+        fh.write("# $1 = wavenumber [cm^-1]\n# $2 = filter function\n\n")
+        for a, b in zip(x, f):
+            fh.write("%.4f %g\n" % (a, b))
+
+
+def limb_geometry(nr, seed=0, obsz=780.0, zmin=3.0, zmax=68.0, nprofiles=1, scan=False):
+    """(nr, 7) limb rays.  scan=True gives the reference's regular tangent-height
+    scan (limb.c), else vpz ~ U[zmin, zmax]."""
+    rng = np.random.default_rng(seed)
+    vpz = np.linspace(zmin, zmax, nr) if scan else rng.uniform(zmin, zmax, nr)
+    g = np.zeros((nr, 7))
+    g[:, 0] = np.arange(nr) % nprofiles
+    g[:, 1] = obsz
+    g[:, 4] = vpz
+    g[:, 6] = 180.0 / np.pi * np.arccos((RE + vpz) / (RE + obsz))
+    return g
+
+
+def nadir_geometry(nr, seed=0, obsz=700.0, lat0=-8.01, lat1=8.01, nprofiles=1):
+    rng = np.random.default_rng(seed)
+    g = np.zeros((nr, 7))
+    g[:, 0] = np.arange(nr) % nprofiles
+    g[:, 1] = obsz
+    g[:, 6] = rng.uniform(lat0, lat1, nr)
+    return g
+
+
+def stack_profiles(atm, ctl, nprofiles, seed=0, dp=0.05, dt=30.0):
+    """Atmosphere holding `nprofiles` perturbed copies of the first profile of
+    `atm`, time stamps 0..nprofiles-1 (profile 0 unperturbed)."""
+    rng = np.random.default_rng(seed)
+    n = atm.np
+    assert n * nprofiles <= abi.NP
+    out = abi.atm_t()
+    out.np = n * nprofiles
+    fields = ("z", "lon", "lat", "p", "t")
+    src = {f: np.ctypeslib.as_array(getattr(atm, f))[:n].copy() for f in fields}
+    q = np.ctypeslib.as_array(atm.q)[:, :n].copy()
+    k = np.ctypeslib.as_array(atm.k)[:, :n].copy()
+    for i in range(nprofiles):
+        s = slice(i * n, (i + 1) * n)
+        fp = 1.0 + (rng.uniform(-dp, dp) if i else 0.0)
+        ft = rng.uniform(-dt, dt) if i else 0.0
+        np.ctypeslib.as_array(out.time)[s] = float(i)
+        for f in ("z", "lon", "lat"):
+            np.ctypeslib.as_array(getattr(out, f))[s] = src[f]
+        np.ctypeslib.as_array(out.p)[s] = src["p"] * fp
+        np.ctypeslib.as_array(out.t)[s] = src["t"] + ft
+        np.ctypeslib.as_array(out.q)[:, s] = q
+        np.ctypeslib.as_array(out.k)[:, s] = k
+    return out

@@ -1,0 +1,133 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "jurassic-gpu_amd"))
+from jurassic_hip import abi  # noqa: E402
+
+_lib = None
+dp = C.POINTER(C.c_double)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_tbl_new.restype = C.c_void_p
+        L.orc_tbl_new.argtypes = [C.c_int] * 5
+        L.orc_tbl_free.argtypes = [C.c_void_p]
+        L.orc_tbl_read_ascii.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_tbl_planck_filt.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_tbl_feed_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, dp, dp, dp, dp]
+        L.orc_tbl_planck_shape.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp]
+        L.orc_formod.argtypes = [C.c_void_p] * 4
+        L.orc_formod_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int] + [dp] * 12 + \
+            [C.POINTER(C.c_int), dp, C.c_int]
+        L.orc_algorithmic_bytes.restype = C.c_double
+        L.orc_algorithmic_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long] + [dp] * 7 + \
+            [C.POINTER(C.c_long)]
+        for name, n in (("orc_ega_eps", 0), ("orc_ctmco2", 4), ("orc_ctmh2o", 5), ("orc_ctmn2", 3),
+                        ("orc_ctmo2", 3), ("orc_planck", 2), ("orc_brightness", 2)):
+            f = getattr(L, name)
+            f.restype = C.c_double
+            if n:
+                f.argtypes = [C.c_double] * n
+        L.orc_ega_eps.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_int, C.c_int]
+        L.orc_traceray.restype = C.c_int
+        L.orc_traceray.argtypes = [C.c_void_p, C.c_void_p] + [dp] * 12
+        L.orc_hydrostatic.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+class Tables:
+    """Owner of one orc_tbl_t."""
+
+    def __init__(self, ng, nd, mp=0, mt=0, mu=0):
+        self.h = lib().orc_tbl_new(ng, nd, mp, mt, mu)
+        self.ng, self.nd = ng, nd
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_tbl_free(self.h)
+            self.h = None
+
+    def read_ascii(self, ctl):
+        return lib().orc_tbl_read_ascii(self.h, C.byref(ctl))
+
+    def planck_filt(self, ctl):
+        return lib().orc_tbl_planck_filt(self.h, C.byref(ctl))
+
+    def feed_rows(self, ig, id_, rows):
+        r = np.ascontiguousarray(rows, dtype=np.float64)
+        cols = [np.ascontiguousarray(r[:, k]) for k in range(4)]
+        lib().orc_tbl_feed_rows(self.h, ig, id_, len(r), *[_p(c) for c in cols])
+
+    def planck_shape(self, id_, nu, f):
+        nu = np.ascontiguousarray(nu, dtype=np.float64)
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        lib().orc_tbl_planck_shape(self.h, id_, len(nu), _p(nu), _p(f))
+
+
+def formod(ctl, atm, obs, tables):
+    lib().orc_formod(C.byref(ctl), C.byref(atm), C.byref(obs), tables.h)
+
+
+def formod_rays(ctl, atm, tables, geom, rad_in=None, serial_trace=False):
+    """geom: (nr, 7) array [time, obsz, obslon, obslat, vpz, vplon, vplat].
+    -> dict(rad, tau, tp (nr,3), np, tsurf)."""
+    g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
+    nr, nd = g.shape[1], ctl.nd
+    rad = np.zeros((nr, nd)) if rad_in is None else np.ascontiguousarray(rad_in, dtype=np.float64).copy()
+    tau = np.zeros((nr, nd))
+    tp = np.zeros((3, nr))
+    npts = np.zeros(nr, dtype=np.int32)
+    tsurf = np.zeros(nr)
+    lib().orc_formod_rays(C.byref(ctl), C.byref(atm), tables.h, nr, nd, *[_p(g[k]) for k in range(7)],
+                          _p(tp[0]), _p(tp[1]), _p(tp[2]), _p(rad), _p(tau),
+                          npts.ctypes.data_as(C.POINTER(C.c_int)), _p(tsurf), int(serial_trace))
+    return dict(rad=rad, tau=tau, tp=np.ascontiguousarray(tp.T), np=npts, tsurf=tsurf)
+
+
+def algorithmic_bytes(ctl, atm, tables, geom):
+    g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
+    nseg = C.c_long(0)
+    b = lib().orc_algorithmic_bytes(C.byref(ctl), C.byref(atm), tables.h, g.shape[1],
+                                    *[_p(g[k]) for k in range(7)], C.byref(nseg))
+    return b, nseg.value
+
+
+def traceray(ctl, atm, geom7):
+    n = abi.NLOS
+    g = np.ascontiguousarray(geom7, dtype=np.float64)
+    out = {k: np.zeros(n) for k in ("z", "lon", "lat", "p", "t", "ds", "k")}
+    q = np.zeros((abi.NG, n))
+    u = np.zeros((abi.NG, n))
+    tsurf = np.zeros(1)
+    tp = np.zeros(3)
+    npts = lib().orc_traceray(C.byref(ctl), C.byref(atm), _p(g), _p(out["z"]), _p(out["lon"]), _p(out["lat"]),
+                              _p(out["p"]), _p(out["t"]), _p(out["ds"]), _p(out["k"]), _p(q), _p(u),
+                              _p(tsurf), _p(tp))
+    res = {k: v[:npts] for k, v in out.items()}
+    res.update(q=q[:ctl.ng, :npts], u=u[:ctl.ng, :npts], np=npts, tsurf=tsurf[0], tp=tp)
+    return res
