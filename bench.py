@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: limb EGA forward model, rays/s on N MI355X.
+
+One "step" = one pass of the hot path (ray tracing + along-path EGA
+integration + epilogue) over one batch of synthetic limb rays that is already
+resident in HBM, followed (N > 1) by the RCCL gather of the per-detector
+radiances to rank 0.  Contract: see the task statement; one JSON line on rank 0.
+
+Workload "limb_1e6" (BASELINE.json configs[2], SURVEY.md 8d "C3"): 1e6 limb
+rays per GPU, view-point altitude ~ U[3, 68] km from 780 km, 5 emitters
+(CO2, H2O, O3, F11, CCl4), 4 channels {792, 832, 1450, 2150} cm^-1 (all four
+continua active), 64 perturbed atmosphere profiles, synthetic emissivity
+tables 33 p x 10 T x ~203 u.  --workload nadir_1e5 is configs[1].
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "jurassic-gpu_amd"), os.path.join(ROOT, "tests")]
+
+import numpy as np  # noqa: E402
+
+
+def build_case(workload, nrays, seed):
+    import common
+    from jurassic_hip import synth
+    if workload.startswith("limb"):
+        nprof = 64
+        geom = synth.limb_geometry(nrays, seed=seed, nprofiles=nprof)
+        case = common.limb_case(geom=geom, nu=common.CTM4_NU, nprofiles=nprof)
+    else:
+        geom = synth.nadir_geometry(nrays, seed=seed)
+        case = common.nadir_case(geom=geom)
+    return case
+
+
+def cpu_baseline(case, target_s=15.0):
+    """Oracle (CPU restatement of CPUdrivers.c) timed on a bounded sample of the
+    same workload, all host cores.  A reported baseline, not the target."""
+    from oracle import orc
+    orc.build()
+    ot = case.oracle_tables(orc)
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    n0 = min(len(case.geom), 2048)
+    t0 = time.perf_counter()
+    orc.formod_rays(case.ctl, case.atm, ot, case.geom[:n0])
+    dt = time.perf_counter() - t0
+    n1 = int(min(len(case.geom), max(n0, n0 * target_s / max(dt, 1e-3))))
+    n1 = max(1088, n1 // 1088 * 1088)
+    n1 = min(n1, len(case.geom))
+    t0 = time.perf_counter()
+    orc.formod_rays(case.ctl, case.atm, ot, case.geom[:n1])
+    dt = time.perf_counter() - t0
+    nb = min(len(case.geom), 4096)
+    ab = orc.algorithmic_bytes(case.ctl, case.atm, ot, case.geom[:nb])
+    return dict(value=n1 / dt, unit="rays/s", cores=cores, kind="port",
+                sample="first %d rays of the workload in packages of 1088, OpenMP over rays incl. tracing, %.1f s"
+                       % (n1, dt)), ab
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="limb_1e6", choices=["limb_1e6", "nadir_1e5"])
+    ap.add_argument("--rays", type=int, default=0, help="rays per GPU (default: the workload's size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from jurassic_hip import lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the library has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    nrays = args.rays or (1_000_000 if args.workload == "limb_1e6" else 100_000)
+    # every rank gets its own, differently seeded shard of rays: weak scaling, no data-path
+    # collective except the final gather of obs.rad
+    case = build_case(args.workload, nrays, seed=1000 + rank)
+    nd = case.ctl.nd
+    model = lib.Model(case.ctl, case.lib_tables(), device=local_rank)
+    model.set_atm(case.atm)
+
+    d_geom = torch.from_numpy(np.ascontiguousarray(case.geom.T)).to(dev)       # [7][nr]
+    d_rad = torch.zeros((nrays, nd), dtype=torch.float64, device=dev)
+    d_tau = torch.zeros((nrays, nd), dtype=torch.float64, device=dev)
+    d_tp = torch.zeros((3, nrays), dtype=torch.float64, device=dev)
+    d_np = torch.zeros(nrays, dtype=torch.int32, device=dev)
+    d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    gathered = [torch.empty_like(d_rad) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        d_rad.zero_()          # input rad carries the NaN mask; all finite here
+        stream = torch.cuda.current_stream().cuda_stream
+        model.formod_device(nrays, d_geom.data_ptr(), d_rad.data_ptr(), d_tau.data_ptr(), d_tp.data_ptr(),
+                            d_np.data_ptr(), d_status.data_ptr(), stream)
+        if world > 1:
+            dist.gather(d_rad, gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    model.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    kms = model.kernel_ms()
+    model.enable_timing(False)
+    if int(d_status.item()) != 0:
+        raise SystemExit("a ray overflowed NLOS")
+    if not bool(torch.isfinite(d_rad).all()):
+        raise SystemExit("non-finite radiance in the benchmark output")
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        total_rays = nrays * world * args.steps
+        out = {
+            "metric": "rays/s (radiance spectra/s) for limb EGA forward model",
+            "value": total_rays / dt,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "rays_per_gpu": nrays, "channels": nd, "emitters": case.ctl.ng,
+                       "tables": "synthetic 33p x 10T x ~203u per (gas, channel), fp32",
+                       "atm_profiles": int(case.atm.np // 91) if args.workload.startswith("limb") else 1,
+                       "sharding": "independent ray ranges per rank, RCCL gather of obs.rad to rank 0"},
+        }
+        ab = None
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ab = cpu_baseline(case)
+            out["cpu_baseline"] = cb
+        if ab is None:
+            from oracle import orc
+            orc.build()
+            ab = orc.algorithmic_bytes(case.ctl, case.atm, case.oracle_tables(orc), case.geom[:4096])
+        a_int = ab["integrate"] / ab["rays"]          # algorithmic bytes per ray, integration kernel
+        a_ray = ab["total"] / ab["rays"]
+        n_launch = max(1, kms["integrate_launches"])
+        rays_per_launch = nrays * args.steps / n_launch
+        avg_ms = kms["integrate_ms"] / n_launch
+        achieved = a_int * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.workload)
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "jur_integrate_kernel", "achieved": achieved, "peak": 8000.0,
+                           "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                           "algorithmic_bytes_per_ray": a_int, "rays_per_launch": rays_per_launch,
+                           "avg_launch_ms": avg_ms,
+                           "trace_kernel_avg_ms": kms["trace_ms"] / max(1, kms["trace_launches"]),
+                           "whole_path_bytes_per_ray": a_ray,
+                           "whole_path_frac": a_ray * out["value"] / world / 8e12}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

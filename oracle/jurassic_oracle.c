@@ -798,10 +798,10 @@ static inline int Lprobe(int n) {                       /* ceil(log2(n-1)) probe
 
 double orc_algorithmic_bytes(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tb, long nr, double const *time,
                              double const *obsz, double const *obslon, double const *obslat, double const *vpz,
-                             double const *vplon, double const *vplat, long *nseg_out) {
-  double total = 0;
+                             double const *vplon, double const *vplat, long *nseg_out, double *trace_part) {
+  double total = 0, ttrace = 0;
   long nseg = 0;
-#pragma omp parallel reduction(+ : total, nseg)
+#pragma omp parallel reduction(+ : total, ttrace, nseg)
   {
     pos_t *los = (pos_t *)malloc(sizeof(pos_t) * NLOS);
 #pragma omp for schedule(dynamic, 16)
@@ -813,9 +813,11 @@ double orc_algorithmic_bytes(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tb, 
       locate_atm(atm, geom[0], &atmIdx, &atmNp);
       int const La = Lprobe(atmNp);
       double bytes = 80 + 24 * ctl->nd;                 /* B_io */
+      double tr = bytes;
       for (int ip = 0; ip < np; ip++) {
         double b_atm = 16 * La + 16 * (3 + ctl->ng + ctl->nw);
         if (ctl->refrac && los[ip].z <= 60 && ip < np - 1) b_atm += 4 * (8 * La + 48);
+        tr += b_atm;
         bytes += b_atm + 8 * (5 + ctl->ng) + ctl->nd * 32.0;
         for (int id = 0; id < ctl->nd; id++)
           for (int ig = 0; ig < ctl->ng; ig++) {
@@ -831,10 +833,12 @@ double orc_algorithmic_bytes(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tb, 
           }
       }
       total += bytes;
+      ttrace += tr;
       nseg += np;
     }
     free(los);
   }
   if (nseg_out) *nseg_out = nseg;
+  if (trace_part) *trace_part = ttrace;
   return total;
 }

@@ -80,12 +80,13 @@ void orc_formod_rays(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tbl,
 
 /* Algorithmic bytes of the reference algorithm for these rays
  * (A_ray summed over rays).  Also returns the number of
- * LOS segments in *nseg. */
+ * LOS segments in *nseg and, in *trace_part, the share that belongs to ray
+ * tracing (B_io + sum of B_atm); the rest belongs to the along-path integration. */
 double orc_algorithmic_bytes(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tbl,
                              long nr,
                              double const *time, double const *obsz, double const *obslon,
                              double const *obslat, double const *vpz, double const *vplon,
-                             double const *vplat, long *nseg);
+                             double const *vplat, long *nseg, double *trace_part);
 
 /* Function-level entry points for known-answer tests. */
 double orc_ega_eps(orc_tbl_t const *tbl, double tau, double t, double u, double p, int ig, int id);

@@ -1,0 +1,89 @@
+"""CPU tests of the C-ABI library: it loads, exports what include/*.h declares,
+agrees on the struct layout, its host-side table logic works, and compute
+entry points fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+import common
+from jurassic_hip import abi, lib, synth
+
+ROOT = common.ROOT
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    L = lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "jurassic_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(jur_\w+|formod\w*)\s*\(", hdr))
+    assert {"formod", "formod_GPU", "formod_pencil", "jur_formod_device", "jur_formod_host"} <= names
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} declared in jurassic_hip.h but not exported"
+
+
+def test_struct_layout_matches_reference_offsets():
+    """sizes/offsets measured on the reference headers."""
+    out = (C.c_size_t * 5)()
+    lib.lib().jur_abi_sizes(out)
+    assert list(out) == [321856, 2841608, 1827848, 100, 30]
+    assert abi.ctl_t.nd.offset == 150004 and abi.ctl_t.nu.offset == 150016
+    assert abi.ctl_t.tblbase.offset == 151216 and abi.ctl_t.refrac.offset == 156264
+    assert abi.ctl_t.write_bbt.offset == 161816 and abi.ctl_t.useGPU.offset == 321828
+    assert abi.atm_t.q.offset == 460800 and abi.atm_t.np.offset == 2841600
+    assert abi.obs_t.tau.offset == 87040 and abi.obs_t.rad.offset == 957440 and abi.obs_t.nr.offset == 1827840
+
+
+def test_table_builder_counts_and_row_rules():
+    rows = synth.table_rows("CO2", 792.0)
+    tb = lib.Tables(1, 1)
+    tb.feed_rows(0, 0, rows)
+    assert tb.entries() == len(rows)
+    # a row that does not increase eps overwrites instead of extending
+    k = 50
+    bad = rows[k].copy()
+    bad[3] *= 0.9
+    tb.feed_rows(0, 0, np.vstack([rows[:k + 1], bad, rows[k + 1:]]))
+    assert tb.entries() == len(rows)
+    # more than TBLNU entries per curve are dropped
+    one = np.array([[100.0, 250.0, 1e15 * 1.01 ** i, 1e-6 * 1.01 ** i] for i in range(400)])
+    tb.feed_rows(0, 0, one)
+    assert tb.entries() == abi.TBLNU
+
+
+def test_table_builder_rejects_too_many_levels():
+    rows = np.array([[float(p), 250.0 + (p % 2), 1e18, 0.1] for p in range(1, 60)])
+    tb = lib.Tables(1, 1)
+    with pytest.raises(lib.JurassicError, match="pressure levels"):
+        tb.feed_rows(0, 0, rows)
+    with pytest.raises(lib.JurassicError):
+        tb.feed_rows(3, 0, rows[:2])
+
+
+def test_ascii_reader_counts_files(tmp_path):
+    case = common.limb_case(missing={(3, 0), (4, 1)})
+    case.write_files(str(tmp_path))
+    tb = lib.Tables(case.ctl.ng, case.ctl.nd)
+    assert tb.read_ascii(case.ctl) == 8
+    tb.read_filters(case.ctl)
+    assert tb.entries() == sum(len(r) for r in case.rows.values())
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    case = common.limb_case()
+    with pytest.raises(lib.JurassicError, match="no HIP device"):
+        lib.Model(case.ctl, case.lib_tables())
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "jurassic-gpu_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert "oracle" not in txt.lower(), f"{f} mentions the oracle"

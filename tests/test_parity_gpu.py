@@ -1,0 +1,248 @@
+"""GPU parity tests: the HIP path, called through the C-ABI of
+libjurassic_hip.so, against the CPU oracle on the same seeded inputs.
+
+Tolerance: north_star asks for 1e-6 relative on radiances.  The kernels keep
+the reference's fp64 operand order (no FMA contraction), so the only expected
+differences are last-bit differences of the device math library (exp, log, pow,
+tanh, asin, atan2, sin, cos) amplified along <= 400 path segments; the tests
+assert 1e-9 relative for radiance/transmittance and exact equality for the
+integer outputs (LOS point counts).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+import common
+from jurassic_hip import abi, synth, textio
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from jurassic_hip import lib
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    assert os.path.exists(lib.SO), "libjurassic_hip.so missing: the HIP path must be built"
+    return lib
+
+
+def run_both(hip, oracle, case, rad_in=None):
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    out = model.formod_host(case.geom, rad_in=rad_in)
+    ref = oracle.formod_rays(case.ctl, case.atm, case.oracle_tables(oracle), case.geom, rad_in=rad_in)
+    model.close()
+    return out, ref
+
+
+def assert_parity(out, ref, rtol=RTOL):
+    assert np.array_equal(out["np"], ref["np"])
+    fin = np.isfinite(ref["rad"])
+    assert np.array_equal(fin, np.isfinite(out["rad"]))
+    assert common.rel_err(out["rad"][fin], ref["rad"][fin]).max() < rtol
+    assert common.rel_err(out["tau"], ref["tau"]).max() < rtol
+    assert np.abs(out["tp"][:, 0] - ref["tp"][:, 0]).max() < 1e-9      # km
+    assert np.abs(out["tp"][:, 1:] - ref["tp"][:, 1:]).max() < 1e-10   # deg
+
+
+def test_limb_example_geometry(hip, oracle):
+    """BASELINE configs[0] shape: the 66 rays of example/limb, 5 emitters, 2 channels."""
+    out, ref = run_both(hip, oracle, common.limb_case())
+    assert_parity(out, ref)
+    gold = textio.read_obs_array(os.path.join(common.GOLD, "limb", "rad.org"), 2)
+    for i, row in enumerate(gold):                      # and the reference's golden geometry columns
+        assert "%g" % out["tp"][i, 0] == "%g" % row[7] and "%g" % out["tp"][i, 2] == "%g" % row[9]
+
+
+def test_nadir_example_geometry_brightness_and_surface(hip, oracle):
+    """example/nadir: ground-hitting rays (surface term) and WRITE_BBT=1."""
+    out, ref = run_both(hip, oracle, common.nadir_case())
+    assert_parity(out, ref)
+    assert np.all((out["rad"] > 150) & (out["rad"] < 320))      # brightness temperatures [K]
+
+
+def test_nadir_random_5000(hip, oracle):
+    out, ref = run_both(hip, oracle, common.nadir_case(geom=synth.nadir_geometry(5000, seed=11)))
+    assert_parity(out, ref)
+
+
+def test_limb_four_continua_64_profiles(hip, oracle):
+    """BASELINE configs[2] shape at a size the oracle does in seconds."""
+    geom = synth.limb_geometry(3000, seed=5, nprofiles=64)
+    out, ref = run_both(hip, oracle, common.limb_case(geom=geom, nu=common.CTM4_NU, nprofiles=64))
+    assert_parity(out, ref)
+
+
+@pytest.mark.parametrize("switches", [dict(ctm_co2=0), dict(ctm_h2o=0), dict(ctm_n2=0, ctm_o2=0),
+                                      dict(ctm_co2=0, ctm_h2o=0, ctm_n2=0, ctm_o2=0), dict(refrac=0),
+                                      dict(rayds=5.0, raydz=1.0), dict(hydz=10.0)])
+def test_control_switches(hip, oracle, switches):
+    geom = synth.limb_geometry(300, seed=2)
+    out, ref = run_both(hip, oracle, common.limb_case(geom=geom, nu=common.CTM4_NU, ctm_auto=1, **switches))
+    assert_parity(out, ref)
+
+
+def test_edge_geometries(hip, oracle):
+    """Ground-hitting limb rays, observer inside the atmosphere looking up and down,
+    zenith view, view point above the atmosphere (no LOS), observer below it."""
+    g = synth.limb_geometry(8, scan=True, zmin=-20.0, zmax=2.0)          # tangent below ground
+    inside_down = np.array([[0, 30.0, 0, 0, 5.0, 0, 3.0]])
+    inside_up = np.array([[0, 10.0, 0, 0, 60.0, 0, 2.0]])
+    zenith = np.array([[0, 20.0, 0, 0, 80.0, 0, 0.0]])
+    too_high = np.array([[0, 780.0, 0, 0, 95.0, 0, 20.0]])
+    below = np.array([[0, -1.0, 0, 0, 10.0, 0, 1.0]])
+    geom = np.vstack([g, inside_down, inside_up, zenith, too_high, below])
+    out, ref = run_both(hip, oracle, common.limb_case(geom=geom))
+    assert_parity(out, ref)
+    assert list(out["np"][-2:]) == [0, 0]
+    assert np.all(out["rad"][-2:] == 0) and np.all(out["tau"][-2:] == 1)
+
+
+def test_nan_mask(hip, oracle):
+    case = common.limb_case()
+    rad_in = np.zeros((len(case.geom), 2))
+    rad_in[0, 0] = np.nan
+    rad_in[65, 1] = -np.inf
+    out, ref = run_both(hip, oracle, case, rad_in=rad_in)
+    assert_parity(out, ref)
+    assert np.isnan(out["rad"][0, 0]) and np.isnan(out["rad"][65, 1])
+
+
+@pytest.mark.parametrize("kw", [dict(table_kw=dict(descending=True)),            # locate_id is ascending-only upstream
+                                dict(table_kw=dict(nlev=1)),                     # np < 2 -> transparent
+                                dict(table_kw=dict(ntemp=1)),                    # nt < 2 -> transparent
+                                dict(table_kw=dict(umax_eps=-1.0)),              # nu < 2 -> transparent
+                                dict(table_kw=dict(nlev=40, ntemp=30, ratio=1.08)),   # maximum extents (TBLNU clips)
+                                dict(missing={(0, 1), (2, 0), (3, 0), (3, 1)})])
+def test_table_shapes(hip, oracle, kw):
+    out, ref = run_both(hip, oracle, common.limb_case(geom=synth.limb_geometry(200, seed=9), **kw))
+    assert_parity(out, ref)
+
+
+def _obs_from_geom(geom, nd):
+    obs = abi.obs_t()
+    obs.nr = len(geom)
+    for k, name in enumerate(("time", "obsz", "obslon", "obslat", "vpz", "vplon", "vplat")):
+        np.ctypeslib.as_array(getattr(obs, name))[:len(geom)] = geom[:, k]
+    np.ctypeslib.as_array(obs.rad)[:] = 7.0      # stale content the call must overwrite
+    np.ctypeslib.as_array(obs.tau)[:] = 7.0
+    return obs
+
+
+def test_drop_in_formod_reads_reference_files(hip, oracle, tmp_path):
+    """formod()/formod_pencil() on ctl_t/atm_t/obs_t with tables and filter
+    functions read from reference-format files (missing files = transparent gas)."""
+    case = common.limb_case(missing={(3, 0), (4, 1)}, filt=None)
+    for nu in common.LIMB_NU:          # the shipped boxcar filter files
+        src = os.path.join(common.GOLD, "limb", "boxcar_%.4f.filt" % nu)
+        x, f = np.loadtxt(src, comments="#").T
+        case.filters[common.LIMB_NU.index(nu)] = (x, f)
+    case.write_files(str(tmp_path), base="boxcar")
+    t_ref = oracle.Tables(case.ctl.ng, case.ctl.nd)
+    assert t_ref.read_ascii(case.ctl) == 2
+    assert t_ref.planck_filt(case.ctl) == 0
+    obs_ref = _obs_from_geom(case.geom, 2)
+    oracle.formod(case.ctl, case.atm, obs_ref, t_ref)
+
+    case.ctl.useGPU = 1
+    obs = _obs_from_geom(case.geom, 2)
+    hip.formod(case.ctl, case.atm, obs)
+    n = obs.nr
+    for name in ("rad", "tau"):
+        a = np.ctypeslib.as_array(getattr(obs, name))[:n]
+        b = np.ctypeslib.as_array(getattr(obs_ref, name))[:n]
+        assert common.rel_err(a[:, :2], b[:, :2]).max() < RTOL
+        assert np.array_equal(a[:, 2:], b[:, 2:])              # upstream clears all ND channels
+    for name in ("tpz", "tplon", "tplat"):
+        assert np.abs(np.ctypeslib.as_array(getattr(obs, name))[:n] -
+                      np.ctypeslib.as_array(getattr(obs_ref, name))[:n]).max() < 1e-9
+
+    one = _obs_from_geom(case.geom, 2)
+    hip.formod_pencil(case.ctl, case.atm, one, 17)
+    assert np.array_equal(np.ctypeslib.as_array(one.rad)[17, :2], np.ctypeslib.as_array(obs.rad)[17, :2])
+    assert np.ctypeslib.as_array(one.rad)[16, 0] == 7.0          # other rays untouched
+
+
+def test_large_batch_properties(hip, oracle):
+    """BASELINE configs[2] at full size (1e6 limb rays, 4 channels, 5 emitters, 64
+    profiles): properties that need no oracle run at that size, plus a sampled
+    oracle comparison."""
+    nr = 1_000_000
+    geom = synth.limb_geometry(nr, seed=1000, nprofiles=64)
+    case = common.limb_case(geom=geom[:8], nu=common.CTM4_NU, nprofiles=64)
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    a = model.formod_host(geom)
+    assert np.isfinite(a["rad"]).all() and np.all((a["tau"] >= 0) & (a["tau"] <= 1))
+    assert a["np"].min() >= 100 and a["np"].max() < abi.NLOS
+    # idempotence and independence of the chunking: bit-identical
+    model.set_chunk_rays(40000)
+    b = model.formod_host(geom)
+    for k in ("rad", "tau", "tp", "np"):
+        assert np.array_equal(a[k], b[k]), k
+    # rays are independent: a permutation of the input permutes the output, bit for bit
+    perm = np.random.default_rng(0).permutation(nr)[:200_000]
+    c = model.formod_host(geom[perm])
+    assert np.array_equal(c["rad"], a["rad"][perm]) and np.array_equal(c["tau"], a["tau"][perm])
+    # sampled comparison with the oracle
+    idx = np.random.default_rng(1).choice(nr, 3000, replace=False)
+    ref = oracle.formod_rays(case.ctl, case.atm, case.oracle_tables(oracle), geom[idx])
+    assert np.array_equal(a["np"][idx], ref["np"])
+    assert common.rel_err(a["rad"][idx], ref["rad"]).max() < RTOL
+    assert common.rel_err(a["tau"][idx], ref["tau"]).max() < RTOL
+    model.close()
+
+
+def test_isothermal_identity_on_device(hip):
+    """rad = B(T) (1 - tau) when T is constant (telescoping of jr_common.h:296-298)."""
+    case = common.limb_case(geom=synth.limb_geometry(20000, seed=4), nu=common.CTM4_NU)
+    np.ctypeslib.as_array(case.atm.t)[:case.atm.np] = 240.0
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    out = model.formod_host(case.geom)
+    c1, c2 = 1.19104259e-8, 1.43877506
+    for d, (x, f) in enumerate(case.filters):
+        b = np.sum(f * c1 * x ** 3 / (np.exp(c2 * x / 240.0) - 1)) / f.sum()
+        assert np.allclose(out["rad"][:, d], b * (1 - out["tau"][:, d]), rtol=1e-11, atol=0)
+    model.close()
+
+
+def test_device_pointer_entry_matches_host_entry(hip):
+    """jur_formod_device on torch-owned HBM buffers and a torch stream."""
+    import torch
+    case = common.limb_case(geom=synth.limb_geometry(5000, seed=8))
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    host = model.formod_host(case.geom)
+    dev = torch.device("cuda", 0)
+    nr, nd = len(case.geom), case.ctl.nd
+    d_geom = torch.from_numpy(np.ascontiguousarray(case.geom.T)).to(dev)
+    d_rad = torch.zeros((nr, nd), dtype=torch.float64, device=dev)
+    d_tau = torch.empty((nr, nd), dtype=torch.float64, device=dev)
+    d_tp = torch.empty((3, nr), dtype=torch.float64, device=dev)
+    d_np = torch.empty(nr, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        model.formod_device(nr, d_geom.data_ptr(), d_rad.data_ptr(), d_tau.data_ptr(), d_tp.data_ptr(),
+                            d_np.data_ptr(), d_st.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    assert int(d_st.item()) == 0
+    assert np.array_equal(d_rad.cpu().numpy(), host["rad"]) and np.array_equal(d_tau.cpu().numpy(), host["tau"])
+    assert np.array_equal(d_tp.cpu().numpy().T, host["tp"]) and np.array_equal(d_np.cpu().numpy(), host["np"])
+    model.close()
+
+
+def test_nlos_overflow_is_reported(hip):
+    """Upstream aborts with 'Too many LOS points!' (jr_common.h:693-695)."""
+    case = common.limb_case(geom=synth.limb_geometry(64, scan=True), raydz=0.2)
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    with pytest.raises(hip.JurassicError, match="Too many LOS points"):
+        model.formod_host(case.geom)
+    model.close()
