@@ -98,8 +98,10 @@ int  jur_formod_device(jur_model_t *m, long nr, double const *d_geom,
  * chunk size (rays per kernel launch) it uses. */
 long jur_model_workspace_bytes(jur_model_t const *m);
 int  jur_model_chunk_rays(jur_model_t const *m);
-/* Tuning knobs (before the first formod call): rays per chunk. */
+/* Tuning knobs: rays per chunk; whether rays are processed in order of their
+ * geometric tangent altitude (default on; results do not depend on it). */
 int  jur_model_set_chunk_rays(jur_model_t *m, int rays);
+int  jur_model_set_sort_rays(jur_model_t *m, int on);
 
 /* Duration in ms of the most recent launch of each kernel on this model,
  * measured with HIP events on the launch stream when profiling is enabled

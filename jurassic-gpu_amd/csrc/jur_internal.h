@@ -12,6 +12,10 @@ extern "C" {
 
 typedef struct { int a, b; } jur_int2;
 typedef struct { float u, eps; } jur_ue_t;
+/* 16-byte descriptors: one load brings the axis value together with the extent
+ * and the offset of the next level of the hierarchy. */
+typedef struct { double p; int nt; int c0; } jur_lvl_t;   /* pressure level: nt curves from curve c0 */
+typedef struct { double t; int nu; int e0; } jur_crv_t;   /* curve: nu (u,eps) entries from entry e0 */
 
 /* Everything about the continua that depends on the channel only, reduced on
  * the host once per model with the reference's own expression order
@@ -41,14 +45,15 @@ typedef struct {
   jur_chan_t const *chan;       /* [nd]                                         */
   double const *sr;             /* [nd][JUR_TBLNS] source function              */
   /* emissivity tables, CSR-like:
-   * pair[g*nd+d] = {np, first level}; plev/lvl per level; tval/crv per curve;
+   * pair[g*nd+d] = {np, first level}; lvl per level; crv per curve;
    * ue = interleaved (u, eps) float pairs, unit stride along u. */
   jur_int2 const *pair;
-  double const *plev;
-  jur_int2 const *lvl;          /* {nt, first curve}                            */
-  double const *tval;
-  jur_int2 const *crv;          /* {nu, first entry}                            */
+  jur_lvl_t const *lvl;
+  jur_crv_t const *crv;
   jur_ue_t const *ue;
+  int sorted_tables;            /* every axis and curve is non-decreasing: any bracket search
+                                   finds what the reference's bisection finds                  */
+  int pad2;
   /* atmosphere, compact SoA of atm_np points */
   int atm_np;
   int pad;
@@ -57,15 +62,20 @@ typedef struct {
   double const *atm_k;          /* [nw][atm_np] */
 } jur_view_t;
 
-/* One chunk of rays handed to the kernels.  All pointers are device memory and
- * already offset to the first ray of the chunk, except `los`. */
+/* One chunk of rays handed to the kernels; all pointers are device memory.
+ * Slot i of the chunk works on ray order[i] of the caller's arrays (order ==
+ * NULL: ray first+i), so that the caller-visible arrays are indexed by ray id
+ * while the workspace arrays (np, tsurf, los) are indexed by slot. */
 typedef struct {
   int n;                        /* rays in this chunk                           */
   int stride;                   /* R: ray stride of the LOS workspace           */
-  double const *geom[7];        /* time, obsz, obslon, obslat, vpz, vplon, vplat */
-  double *tp[3];                /* tpz, tplon, tplat                            */
-  double *rad, *tau;            /* [n][nd]                                      */
-  int *np;                      /* [n] LOS points                               */
+  long first;                   /* first ray id when order == NULL              */
+  int const *order;             /* [n] ray ids of this chunk, or NULL           */
+  double const *geom[7];        /* time, obsz, obslon, obslat, vpz, vplon, vplat; [nr] */
+  double *tp[3];                /* tpz, tplon, tplat; [nr]                      */
+  double *rad, *tau;            /* [nr][nd]                                     */
+  int *np_out;                  /* [nr] LOS points per ray, or NULL             */
+  int *np;                      /* [n] LOS points per slot                      */
   double *tsurf;                /* [n]                                          */
   double *los;                  /* [nfield][JUR_NLOS][stride]                   */
   int *status;                  /* device flag: bit0 = NLOS overflow            */
@@ -74,6 +84,10 @@ typedef struct {
 /* kernel launchers (jur_kernels.hip); return hipError_t as int */
 int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_launch_integrate(jur_view_t const *v, jur_chunk_t const *c, void *stream);
+/* order rays by their geometric tangent altitude: fills order[nr]; `tmp` is a
+ * device scratch of jurk_sort_tmp_bytes(nr) bytes */
+long jurk_sort_tmp_bytes(long nr);
+int jurk_sort_rays(long nr, double const *d_geom, int *d_order, void *tmp, long tmp_bytes, void *stream);
 
 /* host tables (jur_tables.c) */
 typedef struct {
@@ -104,11 +118,10 @@ struct jur_tables {
 /* flatten host tables into the CSR arrays of jur_view_t (malloc'ed) */
 typedef struct {
   long nlevel, ncurve, nentry;
+  int sorted;                   /* all axes and curves non-decreasing           */
   jur_int2 *pair;
-  double *plev;
-  jur_int2 *lvl;
-  double *tval;
-  jur_int2 *crv;
+  jur_lvl_t *lvl;
+  jur_crv_t *crv;
   jur_ue_t *ue;
 } jur_flat_t;
 int  jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out);

@@ -11,12 +11,21 @@
 //                         (:220-224) and the radiance update (:293-300); surface term,
 //                         brightness temperature and the NaN mask are fused in the epilogue
 //                         (CPUdrivers.c:5-24, jr_common.h:193-210).
+//                         Two table-search strategies: WARM (tables whose axes and curves
+//                         are sorted: every bracket is unique, so the search resumes from
+//                         the bracket of the previous segment -- the accumulated
+//                         transmittance only falls, the column only grows) and EXACT (the
+//                         reference's bisections probe for probe, for unsorted tables).
+//   jur_raykey_kernel     geometric tangent altitude per ray; rays are then processed in
+//                         that order (hipCUB radix sort) so that the lanes of a wavefront
+//                         walk similar paths.
 //
 // All arithmetic is IEEE fp64 with the reference's operand order; tables are fp32 in memory.
 // Compiled with -ffp-contract=off so that no fused multiply-adds are formed that the
 // reference's x86-64 build does not form.
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include "jur_internal.h"
 
 #define NLOS JUR_NLOS
@@ -93,15 +102,16 @@ __device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, dou
 // ray tracing, one lane per ray
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t c) {
-  int const r = blockIdx.x * blockDim.x + threadIdx.x;
+  int const r = blockIdx.x * blockDim.x + threadIdx.x;   // slot in the chunk
   if (r >= c.n) return;
+  long const ray = c.order ? (long)c.order[r] : c.first + r;
   size_t const R = (size_t)c.stride;
   double *const los = c.los;
   auto F = [&](int field, int ip) -> double & { return los[((size_t)field * NLOS + ip) * R + r]; };
   int const f_k = JUR_F_K, f_u = JUR_F_K + v.nw;
 
-  double const time = c.geom[0][r], obsz = c.geom[1][r], obslon = c.geom[2][r], obslat = c.geom[3][r],
-               vpz = c.geom[4][r], vplon = c.geom[5][r], vplat = c.geom[6][r];
+  double const time = c.geom[0][ray], obsz = c.geom[1][ray], obslon = c.geom[2][ray], obslat = c.geom[3][ray],
+               vpz = c.geom[4][ray], vplon = c.geom[5][ray], vplat = c.geom[6][ray];
   double tsurf = -999;
   double tpz = vpz, tplon = vplon, tplat = vplat;
   int np = 0;
@@ -298,79 +308,172 @@ __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t
 
   c.np[r] = np;
   c.tsurf[r] = tsurf;
-  c.tp[0][r] = tpz;
-  c.tp[1][r] = tplon;
-  c.tp[2][r] = tplat;
+  if (c.np_out) c.np_out[ray] = np;
+  c.tp[0][ray] = tpz;
+  c.tp[1][ray] = tplon;
+  c.tp[2][ray] = tplat;
 }
 
 // ---------------------------------------------------------------------------------------
-// emissivity-growth look-up
+// emissivity-growth look-up (ega_eps, jr_common.h:237-268)
 // ---------------------------------------------------------------------------------------
-// ascending-only bracket search on a double axis (locate_id, jr_common.h:106-114)
-__device__ __forceinline__ int locate_up(double const *__restrict__ xx, int n, double x) {
+struct __attribute__((aligned(16))) Lvl { double p; int nt; int c0; };
+struct __attribute__((aligned(16))) Crv { double t; int nu; int e0; };
+struct __attribute__((aligned(8))) Ue { float u; float eps; };
+static_assert(sizeof(Lvl) == sizeof(jur_lvl_t) && sizeof(Crv) == sizeof(jur_crv_t) && sizeof(Ue) == sizeof(jur_ue_t), "layout");
+
+template <bool ON_EPS>
+__device__ __forceinline__ double ukey(Ue const &e) { return ON_EPS ? (double)e.eps : (double)e.u; }
+
+// EXACT: the reference's bisection (locate_tbl_id, jr_common.h:116-125)
+template <bool ON_EPS>
+__device__ __forceinline__ int bisect_curve(Ue const *__restrict__ e, int n, double x) {
   int ilo = 0, ihi = n - 1;
   while (ihi > ilo + 1) {
     int const i = (ihi + ilo) >> 1;
-    if (xx[i] > x) ihi = i; else ilo = i;
+    if (ukey<ON_EPS>(e[i]) > x) ihi = i; else ilo = i;
   }
   return ilo;
 }
 
-// u at which curve `e` reaches emissivity eps (get_u, jr_common.h:179-185)
-__device__ __forceinline__ double curve_u_of_eps(jur_ue_t const *__restrict__ e, int n, double eps) {
-  int ilo = 0, ihi = n - 1;
-  while (ihi > ilo + 1) {
-    int const i = (ihi + ilo) >> 1;
-    if ((double)e[i].eps > eps) ihi = i; else ilo = i;
+// WARM: move bracket i (entries a = e[i], b = e[i+1] already loaded) to the one that holds x:
+// key(e[i]) <= x < key(e[i+1]), clamped to [0, n-2].  Gallop, then bisect inside the gap.
+template <bool ON_EPS>
+__device__ __forceinline__ void seek_curve(Ue const *__restrict__ e, int n, double x, int &i, Ue &a, Ue &b) {
+  if (x >= ukey<ON_EPS>(b)) {
+    if (i >= n - 2) return;
+    int lo = i + 1, hi, step = 1;
+    for (;;) {
+      hi = lo + step;
+      if (hi >= n - 1) { hi = n - 1; break; }
+      if (ukey<ON_EPS>(e[hi]) > x) break;
+      lo = hi;
+      step <<= 1;
+    }
+    while (hi > lo + 1) {
+      int const mid = (lo + hi) >> 1;
+      if (ukey<ON_EPS>(e[mid]) > x) hi = mid; else lo = mid;
+    }
+    i = lo; a = e[lo]; b = e[lo + 1];
+  } else if (x < ukey<ON_EPS>(a)) {
+    if (i <= 0) return;
+    int hi = i, lo, step = 1;
+    for (;;) {
+      lo = hi - step;
+      if (lo <= 0) { lo = 0; break; }
+      if (ukey<ON_EPS>(e[lo]) <= x) break;
+      hi = lo;
+      step <<= 1;
+    }
+    while (hi > lo + 1) {
+      int const mid = (lo + hi) >> 1;
+      if (ukey<ON_EPS>(e[mid]) > x) hi = mid; else lo = mid;
+    }
+    i = lo; a = e[lo]; b = e[lo + 1];
   }
-  jur_ue_t const a = e[ilo], b = e[ilo + 1];
-  return lip((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps);
 }
 
-// emissivity of curve `e` at column density u (get_eps, jr_common.h:156-177)
-__device__ __forceinline__ double curve_eps_of_u(jur_ue_t const *__restrict__ e, int n, double u) {
-  int ilo = 0, ihi = n - 1;
-  while (ihi > ilo + 1) {
-    int const i = (ihi + ilo) >> 1;
-    if ((double)e[i].u > u) ihi = i; else ilo = i;
+// one (p,T) corner: u at which the curve reaches `eps`, then the curve's emissivity at that u
+// plus the segment's column (get_u, get_eps: jr_common.h:156-185)
+template <bool WARM>
+__device__ __forceinline__ double corner_eps(Ue const *__restrict__ e, int n, double eps, double u, int &idx) {
+  Ue a, b;
+  int i;
+  if (WARM) {
+    i = min(idx, n - 2);
+    a = e[i]; b = e[i + 1];
+    seek_curve<true>(e, n, eps, i, a, b);
+    idx = i;
+  } else {
+    i = bisect_curve<true>(e, n, eps);
+    a = e[i]; b = e[i + 1];
   }
-  jur_ue_t const a = e[ilo], b = e[ilo + 1];
-  return lip((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, u);
+  double const uc = lip((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps);
+  double const x = uc + u;
+  if (WARM) {
+    seek_curve<false>(e, n, x, i, a, b);
+  } else {
+    i = bisect_curve<false>(e, n, x);
+    a = e[i]; b = e[i + 1];
+  }
+  return c01(lip((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, x));
 }
 
-// segment transmittance of gas g in channel d given the transmittance accumulated so far
-// (ega_eps, jr_common.h:237-268)
-__device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, double tau, double t, double u, double p) {
+// per-gas search state carried from segment to segment (WARM only):
+//   br = ipr | it0 << 8 | it1 << 16,  ia = idx00 | idx01 << 16,  ib = idx10 | idx11 << 16
+template <bool WARM>
+__device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, double tau, double t, double u, double p,
+                                          unsigned &br, unsigned &ia, unsigned &ib) {
   if (tau < 1e-9) return 0.;
   jur_int2 const pr = v.pair[pair_idx];
   if (pr.a < 2) return 1.;
-  double const *pl = v.plev + pr.b;
-  int const ipr = locate_up(pl, pr.a, p);
-  jur_int2 const l0 = v.lvl[pr.b + ipr], l1 = v.lvl[pr.b + ipr + 1];
-  if (l0.a < 2 || l1.a < 2) return 1.;
-  double const *t0 = v.tval + l0.b, *t1 = v.tval + l1.b;
-  int const it0 = locate_up(t0, l0.a, t);
-  jur_int2 const c00 = v.crv[l0.b + it0], c01_ = v.crv[l0.b + it0 + 1];
-  if (c00.a < 2 || c01_.a < 2) return 1.;
-  int const it1 = locate_up(t1, l1.a, t);
-  jur_int2 const c10 = v.crv[l1.b + it1], c11 = v.crv[l1.b + it1 + 1];
-  if (c10.a < 2 || c11.a < 2) return 1.;
+  Lvl const *const lv = reinterpret_cast<Lvl const *>(v.lvl) + pr.b;
+  int ipr;
+  Lvl l0, l1;
+  if (WARM) {
+    ipr = min((int)(br & 0xffu), pr.a - 2);
+    l0 = lv[ipr]; l1 = lv[ipr + 1];
+    while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = lv[ipr]; }
+    while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = lv[ipr + 1]; }
+  } else {  // locate_id, jr_common.h:106-114 (ascending-only bisection, whatever the axis looks like)
+    int ilo = 0, ihi = pr.a - 1;
+    while (ihi > ilo + 1) {
+      int const i = (ihi + ilo) >> 1;
+      if (lv[i].p > p) ihi = i; else ilo = i;
+    }
+    ipr = ilo;
+    l0 = lv[ipr]; l1 = lv[ipr + 1];
+  }
+  if (WARM) br = (br & ~0xffu) | (unsigned)ipr;
+  if (l0.nt < 2 || l1.nt < 2) return 1.;
+  Crv const *const cv0 = reinterpret_cast<Crv const *>(v.crv) + l0.c0;
+  Crv const *const cv1 = reinterpret_cast<Crv const *>(v.crv) + l1.c0;
+  int it0, it1;
+  Crv c00, c01_, c10, c11;
+  if (WARM) {
+    it0 = min((int)((br >> 8) & 0xffu), l0.nt - 2);
+    c00 = cv0[it0]; c01_ = cv0[it0 + 1];
+    while (t < c00.t && it0 > 0) { --it0; c01_ = c00; c00 = cv0[it0]; }
+    while (t >= c01_.t && it0 < l0.nt - 2) { ++it0; c00 = c01_; c01_ = cv0[it0 + 1]; }
+    it1 = min((int)((br >> 16) & 0xffu), l1.nt - 2);
+    c10 = cv1[it1]; c11 = cv1[it1 + 1];
+    while (t < c10.t && it1 > 0) { --it1; c11 = c10; c10 = cv1[it1]; }
+    while (t >= c11.t && it1 < l1.nt - 2) { ++it1; c10 = c11; c11 = cv1[it1 + 1]; }
+    br = (unsigned)ipr | ((unsigned)it0 << 8) | ((unsigned)it1 << 16);
+    if (c00.nu < 2 || c01_.nu < 2 || c10.nu < 2 || c11.nu < 2) return 1.;
+  } else {
+    int ilo = 0, ihi = l0.nt - 1;
+    while (ihi > ilo + 1) {
+      int const i = (ihi + ilo) >> 1;
+      if (cv0[i].t > t) ihi = i; else ilo = i;
+    }
+    it0 = ilo;
+    c00 = cv0[it0]; c01_ = cv0[it0 + 1];
+    if (c00.nu < 2 || c01_.nu < 2) return 1.;
+    ilo = 0; ihi = l1.nt - 1;
+    while (ihi > ilo + 1) {
+      int const i = (ihi + ilo) >> 1;
+      if (cv1[i].t > t) ihi = i; else ilo = i;
+    }
+    it1 = ilo;
+    c10 = cv1[it1]; c11 = cv1[it1 + 1];
+    if (c10.nu < 2 || c11.nu < 2) return 1.;
+  }
 
   double const eps = 1 - tau;
-  jur_ue_t const *e00 = v.ue + c00.b, *e01 = v.ue + c01_.b, *e10 = v.ue + c10.b, *e11 = v.ue + c11.b;
-  double const u00 = curve_u_of_eps(e00, c00.a, eps);
-  double const u01 = curve_u_of_eps(e01, c01_.a, eps);
-  double const u10 = curve_u_of_eps(e10, c10.a, eps);
-  double const u11 = curve_u_of_eps(e11, c11.a, eps);
-
-  double const eps00 = c01(curve_eps_of_u(e00, c00.a, u00 + u));
-  double const eps01 = c01(curve_eps_of_u(e01, c01_.a, u01 + u));
-  double const eps10 = c01(curve_eps_of_u(e10, c10.a, u10 + u));
-  double const eps11 = c01(curve_eps_of_u(e11, c11.a, u11 + u));
-
-  double const eps_p0 = c01(lip(t0[it0], eps00, t0[it0 + 1], eps01, t));
-  double const eps_p1 = c01(lip(t1[it1], eps10, t1[it1 + 1], eps11, t));
-  double const eps_t = c01(lip(pl[ipr], eps_p0, pl[ipr + 1], eps_p1, p));
+  Ue const *const ue = reinterpret_cast<Ue const *>(v.ue);
+  int i00 = (int)(ia & 0xffffu), i01 = (int)(ia >> 16), i10 = (int)(ib & 0xffffu), i11 = (int)(ib >> 16);
+  double const eps00 = corner_eps<WARM>(ue + c00.e0, c00.nu, eps, u, i00);
+  double const eps01 = corner_eps<WARM>(ue + c01_.e0, c01_.nu, eps, u, i01);
+  double const eps10 = corner_eps<WARM>(ue + c10.e0, c10.nu, eps, u, i10);
+  double const eps11 = corner_eps<WARM>(ue + c11.e0, c11.nu, eps, u, i11);
+  if (WARM) {
+    ia = (unsigned)i00 | ((unsigned)i01 << 16);
+    ib = (unsigned)i10 | ((unsigned)i11 << 16);
+  }
+  double const eps_p0 = c01(lip(c00.t, eps00, c01_.t, eps01, t));
+  double const eps_p1 = c01(lip(c10.t, eps10, c11.t, eps11, t));
+  double const eps_t = c01(lip(l0.p, eps_p0, l1.p, eps_p1, p));
   return (1. - eps_t) / tau;
 }
 
@@ -415,14 +518,16 @@ __device__ __forceinline__ double planck_src(double const *__restrict__ sr, doub
 // ---------------------------------------------------------------------------------------
 // along-path integration, one lane per (ray, channel)
 // ---------------------------------------------------------------------------------------
-template <int NGT>
+template <int NGT, bool WARM>
 __global__ __launch_bounds__(256) void jur_integrate_kernel(jur_view_t v, jur_chunk_t c) {
   long const lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int const nd = v.nd;
   if (lane >= (long)c.n * nd) return;
-  int const r = (int)(lane / nd), d = (int)(lane - (long)r * nd);
+  int const r = (int)(lane / nd), d = (int)(lane - (long)r * nd);   // slot, channel
+  long const ray = c.order ? (long)c.order[r] : c.first + r;
   size_t const R = (size_t)c.stride;
-  double const *const los = c.los;
+  size_t const fs = (size_t)NLOS * R;
+  double const *const los = c.los + r;
   jur_chan_t const ch = v.chan[d];
   double const *const sr = v.sr + (size_t)d * TBLNS;
   int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
@@ -430,22 +535,52 @@ __global__ __launch_bounds__(256) void jur_integrate_kernel(jur_view_t v, jur_ch
   bool const do_co2 = (v.fourbit & 8) && ch.co2_on, do_h2o = (v.fourbit & 4) && ch.h2o_on,
              do_n2 = (v.fourbit & 2) && ch.n2_on, do_o2 = (v.fourbit & 1) && ch.o2_on;
 
-  bool const masked = !isfinite(c.rad[lane]);
+  size_t const oidx = (size_t)ray * nd + d;
+  bool const masked = !isfinite(c.rad[oidx]);
   double rad = 0.0, tau = 1.0;
   double tau_path[NGT];
+  unsigned br[NGT], ia[NGT], ib[NGT];
 #pragma unroll
-  for (int g = 0; g < NGT; g++) tau_path[g] = 1.0;
+  for (int g = 0; g < NGT; g++) { tau_path[g] = 1.0; br[g] = 0; ia[g] = 0; ib[g] = 0; }
 
   int const np = c.np[r];
+  // segment state of the current point; the next point's is fetched while this one is worked on
+  double p = 0, t = 0, ds = 0, kx = 0, qh = 0, ug[NGT];
+  auto fetch = [&](int ip, double &p_, double &t_, double &ds_, double &k_, double &q_, double (&u_)[NGT]) {
+    size_t const o = (size_t)ip * R;
+    p_ = los[JUR_F_P * fs + o];
+    t_ = los[JUR_F_T * fs + o];
+    ds_ = los[JUR_F_DS * fs + o];
+    k_ = los[f_k * fs + o];
+    if (do_h2o) q_ = los[JUR_F_QH2O * fs + o];
+#pragma unroll
+    for (int g = 0; g < NGT; g++)
+      if (g < ng) u_[g] = los[(f_u + g) * fs + o];
+  };
+#pragma unroll
+  for (int g = 0; g < NGT; g++) ug[g] = 0;
+  if (np > 0) fetch(0, p, t, ds, kx, qh, ug);
+
   for (int ip = 0; ip < np; ++ip) {
-    size_t const o = (size_t)ip * R + r;
-    size_t const fs = (size_t)NLOS * R;
-    double const p = los[JUR_F_P * fs + o], t = los[JUR_F_T * fs + o], ds = los[JUR_F_DS * fs + o];
+    double pn = 0, tn = 0, dsn = 0, kn = 0, qn = 0, un[NGT];
+#pragma unroll
+    for (int g = 0; g < NGT; g++) un[g] = 0;
+    if (ip + 1 < np) fetch(ip + 1, pn, tn, dsn, kn, qn, un);
 
     // extinction and continua (jr_continua_core.mv4g.h:1-14)
-    double beta_ds = los[f_k * fs + o] * ds;
-    if (do_co2) beta_ds += ctm_co2(ch, p, t, los[(f_u + v.ig_co2) * fs + o]);
-    if (do_h2o) beta_ds += ctm_h2o(ch, p, t, los[JUR_F_QH2O * fs + o], los[(f_u + v.ig_h2o) * fs + o]);
+    double beta_ds = kx * ds;
+    if (do_co2) {
+      double uco2 = 0;
+#pragma unroll
+      for (int g = 0; g < NGT; g++) if (g == v.ig_co2) uco2 = ug[g];
+      beta_ds += ctm_co2(ch, p, t, uco2);
+    }
+    if (do_h2o) {
+      double uh2o = 0;
+#pragma unroll
+      for (int g = 0; g < NGT; g++) if (g == v.ig_h2o) uh2o = ug[g];
+      beta_ds += ctm_h2o(ch, p, t, qh, uh2o);
+    }
     if (do_n2) beta_ds += ctm_n2(ch, p, t) * ds;
     if (do_o2) beta_ds += ctm_o2(ch, p, t) * ds;
 
@@ -454,7 +589,7 @@ __global__ __launch_bounds__(256) void jur_integrate_kernel(jur_view_t v, jur_ch
 #pragma unroll
     for (int g = 0; g < NGT; g++) {
       if (g < ng) {
-        double const eps = ega_eps(v, g * nd + d, tau_path[g], t, los[(f_u + g) * fs + o], p);
+        double const eps = ega_eps<WARM>(v, g * nd + d, tau_path[g], t, ug[g], p, br[g], ia[g], ib[g]);
         tau_path[g] *= eps;
         tau_gas *= eps;
       }
@@ -466,14 +601,39 @@ __global__ __launch_bounds__(256) void jur_integrate_kernel(jur_view_t v, jur_ch
       rad += src * eps * tau;
       tau *= (1. - eps);
     }
+    p = pn; t = tn; ds = dsn; kx = kn; qh = qn;
+#pragma unroll
+    for (int g = 0; g < NGT; g++) ug[g] = un[g];
   }
 
   double const tsurf = c.tsurf[r];
   if (tsurf > 0.) rad += planck_src(sr, tsurf) * tau;  // jr_common.h:227-234
   if (v.write_bbt) rad = JUR_C2 * ch.nu / log1p((JUR_C1 * ch.nu * ch.nu * ch.nu) / rad);  // :188-190
   if (masked) rad = __builtin_nan("");
-  c.rad[lane] = rad;
-  c.tau[lane] = tau;
+  c.rad[oidx] = rad;
+  c.tau[oidx] = tau;
+}
+
+// ---------------------------------------------------------------------------------------
+// ray ordering key: altitude of the straight line's closest approach to the Earth's centre
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jur_raykey_kernel(long nr, double const *__restrict__ geom,
+                                                         float *__restrict__ key, int *__restrict__ id) {
+  long const r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nr) return;
+  double xo[3], xv[3], e[3];
+  geo2cart(geom[1 * nr + r], geom[2 * nr + r], geom[3 * nr + r], xo);
+  geo2cart(geom[4 * nr + r], geom[5 * nr + r], geom[6 * nr + r], xv);
+  for (int i = 0; i < 3; i++) e[i] = xv[i] - xo[i];
+  double const n = norm3(e);
+  double h = norm3(xo) - JUR_RE;
+  if (n > 0) {
+    double s = 0;
+    for (int i = 0; i < 3; i++) s -= xo[i] * e[i] / n;
+    if (s > 0) h = sqrt(fmax(xo[0] * xo[0] + xo[1] * xo[1] + xo[2] * xo[2] - s * s, 0.)) - JUR_RE;
+  }
+  key[r] = (float)h;
+  id[r] = (int)r;
 }
 
 }  // namespace
@@ -492,7 +652,11 @@ extern "C" int jurk_launch_integrate(jur_view_t const *v, jur_chunk_t const *c, 
   long const lanes = (long)c->n * v->nd;
   int const grid = (int)((lanes + block - 1) / block);
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(N) hipLaunchKernelGGL(jur_integrate_kernel<N>, dim3(grid), dim3(block), 0, s, *v, *c)
+#define LAUNCH(N)                                                                                         \
+  do {                                                                                                    \
+    if (v->sorted_tables) hipLaunchKernelGGL((jur_integrate_kernel<N, true>), dim3(grid), dim3(block), 0, s, *v, *c); \
+    else hipLaunchKernelGGL((jur_integrate_kernel<N, false>), dim3(grid), dim3(block), 0, s, *v, *c);    \
+  } while (0)
   if (v->ng <= 1) LAUNCH(1);
   else if (v->ng <= 2) LAUNCH(2);
   else if (v->ng <= 3) LAUNCH(3);
@@ -505,4 +669,31 @@ extern "C" int jurk_launch_integrate(jur_view_t const *v, jur_chunk_t const *c, 
   else LAUNCH(JUR_NG);
 #undef LAUNCH
   return (int)hipGetLastError();
+}
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" long jurk_sort_tmp_bytes(long nr) {
+  size_t cub = 0;
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (float const *)nullptr, (float *)nullptr, (int const *)nullptr,
+                                         (int *)nullptr, (int)nr) != hipSuccess)
+    cub = 64 * (size_t)nr + (1 << 20);
+  return (long)(3 * align_up(sizeof(float) * (size_t)nr) + align_up(cub) + 256);
+}
+
+extern "C" int jurk_sort_rays(long nr, double const *d_geom, int *d_order, void *tmp, long tmp_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  size_t const seg = align_up(sizeof(float) * (size_t)nr);
+  char *base = (char *)tmp;
+  float *key_in = (float *)base, *key_out = (float *)(base + seg);
+  int *id_in = (int *)(base + 2 * seg);
+  void *cub_tmp = base + 3 * seg;
+  size_t cub_bytes = (size_t)tmp_bytes - 3 * seg;
+  int const block = 256;
+  hipLaunchKernelGGL(jur_raykey_kernel, dim3((unsigned)((nr + block - 1) / block)), dim3(block), 0, s, nr, d_geom, key_in,
+                     id_in);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, key_in, key_out, id_in, d_order, (int)nr, 0, 32, s);
+  return (int)e;
 }

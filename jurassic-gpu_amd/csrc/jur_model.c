@@ -29,7 +29,7 @@ struct jur_model {
   jur_view_t view;              /* device pointers                               */
   long table_bytes;
   /* device allocations owned by the model */
-  void *d_chan, *d_sr, *d_pair, *d_plev, *d_lvl, *d_tval, *d_crv, *d_ue;
+  void *d_chan, *d_sr, *d_pair, *d_lvl, *d_crv, *d_ue;
   void *d_atm;                  /* one slab for the compact atmosphere           */
   int atm_cap;
   /* per-call workspace */
@@ -40,6 +40,11 @@ struct jur_model {
   double *d_tsurf;
   int *d_status;
   long los_bytes;
+  /* ray ordering */
+  int sort_rays;                /* 1: process rays in order of tangent altitude  */
+  int *d_order;
+  void *d_sort_tmp;
+  long order_cap, sort_tmp_bytes;
   /* staging for the host entry */
   double *d_io;                 /* geom[7][cap] tp[3][cap] rad/tau[cap][nd]      */
   int *d_io_np;
@@ -127,25 +132,23 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   if (rc) { jur_model_destroy(m); return rc; }
   long const npair = (long)ctl->ng * ctl->nd;
   rc = upload(&m->d_pair, fl.pair, sizeof(jur_int2) * (npair > 0 ? npair : 1));
-  if (!rc) rc = upload(&m->d_plev, fl.plev, sizeof(double) * (fl.nlevel + 1));
-  if (!rc) rc = upload(&m->d_lvl, fl.lvl, sizeof(jur_int2) * (fl.nlevel + 1));
-  if (!rc) rc = upload(&m->d_tval, fl.tval, sizeof(double) * (fl.ncurve + 1));
-  if (!rc) rc = upload(&m->d_crv, fl.crv, sizeof(jur_int2) * (fl.ncurve + 1));
+  if (!rc) rc = upload(&m->d_lvl, fl.lvl, sizeof(jur_lvl_t) * (fl.nlevel + 2));
+  if (!rc) rc = upload(&m->d_crv, fl.crv, sizeof(jur_crv_t) * (fl.ncurve + 2));
   if (!rc) rc = upload(&m->d_ue, fl.ue, sizeof(jur_ue_t) * (fl.nentry + 2));
+  v->sorted_tables = fl.sorted;
   m->table_bytes = (long)(sizeof(jur_ue_t) * fl.nentry + 16 * fl.ncurve + 16 * fl.nlevel + 8 * npair);
   jur_flat_free(&fl);
   if (rc) { jur_model_destroy(m); return rc; }
   v->chan = (jur_chan_t const *)m->d_chan;
   v->sr = (double const *)m->d_sr;
   v->pair = (jur_int2 const *)m->d_pair;
-  v->plev = (double const *)m->d_plev;
-  v->lvl = (jur_int2 const *)m->d_lvl;
-  v->tval = (double const *)m->d_tval;
-  v->crv = (jur_int2 const *)m->d_crv;
+  v->lvl = (jur_lvl_t const *)m->d_lvl;
+  v->crv = (jur_crv_t const *)m->d_crv;
   v->ue = (jur_ue_t const *)m->d_ue;
 
   m->nfield = JUR_F_K + v->nw + v->ng;
   m->chunk_rays = 131072;
+  m->sort_rays = 1;
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { jur_set_error("hipStreamCreate failed"); jur_model_destroy(m); return JUR_EHIP; }
   if ((rc = upload((void **)&m->d_status, NULL, sizeof(int)))) { jur_model_destroy(m); return rc; }
   HIPCHK(hipMemset(m->d_status, 0, sizeof(int)));
@@ -173,7 +176,7 @@ int jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device)
 void jur_model_destroy(jur_model_t *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
-  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_plev, m->d_lvl, m->d_tval, m->d_crv, m->d_ue, m->d_atm,
+  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_lvl, m->d_crv, m->d_ue, m->d_atm, m->d_order, m->d_sort_tmp,
                   m->d_los, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
     if (ptrs[i]) (void)hipFree(ptrs[i]);
@@ -283,6 +286,8 @@ static int ensure_workspace(jur_model_t *m, long nr) {
 long jur_model_workspace_bytes(jur_model_t const *m) { return m->los_bytes; }
 int jur_model_chunk_rays(jur_model_t const *m) { return m->chunk_rays; }
 
+int jur_model_set_sort_rays(jur_model_t *m, int on) { m->sort_rays = on ? 1 : 0; return JUR_OK; }
+
 int jur_model_set_chunk_rays(jur_model_t *m, int rays) {
   if (rays < 64 || rays > (1 << 22)) { jur_set_error("chunk_rays must be in 64..4194304"); return JUR_EINVAL; }
   m->chunk_rays = (rays + 63) / 64 * 64;
@@ -331,16 +336,35 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   long const R = m->los_bytes / ((long)sizeof(double) * m->nfield * JUR_NLOS);
-  int const nd = m->view.nd;
+  int const *order = NULL;
+  if (m->sort_rays && nr > 64) {
+    /* similar rays side by side: equal trip counts inside a wavefront and neighbouring
+     * table/profile addresses across its lanes */
+    long const need = jurk_sort_tmp_bytes(nr);
+    if (nr > m->order_cap || need > m->sort_tmp_bytes) {
+      if (m->d_order) (void)hipFree(m->d_order);
+      if (m->d_sort_tmp) (void)hipFree(m->d_sort_tmp);
+      m->d_order = NULL; m->d_sort_tmp = NULL; m->order_cap = 0; m->sort_tmp_bytes = 0;
+      HIPCHK(hipMalloc((void **)&m->d_order, sizeof(int) * (size_t)nr));
+      HIPCHK(hipMalloc(&m->d_sort_tmp, (size_t)need));
+      m->order_cap = nr; m->sort_tmp_bytes = need;
+    }
+    int const e = jurk_sort_rays(nr, d_geom, m->d_order, m->d_sort_tmp, m->sort_tmp_bytes, s);
+    if (e) { jur_set_error("ray sort failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
+    order = m->d_order;
+  }
   for (long r0 = 0; r0 < nr; r0 += R) {
     jur_chunk_t c;
     c.n = (int)((nr - r0 < R) ? nr - r0 : R);
     c.stride = (int)R;
-    for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * nr + r0;
-    for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * nr + r0;
-    c.rad = d_rad + (size_t)r0 * nd;
-    c.tau = d_tau + (size_t)r0 * nd;
-    c.np = d_np ? d_np + r0 : m->d_np;
+    c.first = r0;
+    c.order = order ? order + r0 : NULL;
+    for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * nr;
+    for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * nr;
+    c.rad = d_rad;
+    c.tau = d_tau;
+    c.np_out = d_np;
+    c.np = m->d_np;
     c.tsurf = m->d_tsurf;
     c.los = m->d_los;
     c.status = d_status ? d_status : m->d_status;

@@ -318,34 +318,40 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
   if (nentry >= 0x7fffffffL) { jur_set_error("tables too large for 32-bit offsets (%ld entries)", nentry); return JUR_EINVAL; }
   out->nlevel = nlevel; out->ncurve = ncurve; out->nentry = nentry;
   out->pair = (jur_int2 *)calloc(npair > 0 ? npair : 1, sizeof(jur_int2));
-  out->plev = (double *)calloc(nlevel + 1, sizeof(double));
-  out->lvl = (jur_int2 *)calloc(nlevel + 1, sizeof(jur_int2));
-  out->tval = (double *)calloc(ncurve + 1, sizeof(double));
-  out->crv = (jur_int2 *)calloc(ncurve + 1, sizeof(jur_int2));
+  out->lvl = (jur_lvl_t *)calloc(nlevel + 2, sizeof(jur_lvl_t));
+  out->crv = (jur_crv_t *)calloc(ncurve + 2, sizeof(jur_crv_t));
   out->ue = (jur_ue_t *)calloc(nentry + 2, sizeof(jur_ue_t));
-  if (!out->pair || !out->plev || !out->lvl || !out->tval || !out->crv || !out->ue) { jur_flat_free(out); return JUR_ENOMEM; }
+  if (!out->pair || !out->lvl || !out->crv || !out->ue) { jur_flat_free(out); return JUR_ENOMEM; }
   long L = 0, K = 0, E = 0;
+  int sorted = 1;
   for (long i = 0; i < npair; i++) {
     jur_pair_t const *pr = &tb->pair[i];
     out->pair[i].a = pr->np;
     out->pair[i].b = (int)L;
     for (int ip = 0; ip < pr->np; ip++, L++) {
-      out->plev[L] = pr->lv[ip].p;
-      out->lvl[L].a = pr->lv[ip].nt;
-      out->lvl[L].b = (int)K;
+      out->lvl[L].p = pr->lv[ip].p;
+      out->lvl[L].nt = pr->lv[ip].nt;
+      out->lvl[L].c0 = (int)K;
+      if (ip > 0 && !(pr->lv[ip - 1].p <= pr->lv[ip].p)) sorted = 0;
       for (int it = 0; it < pr->lv[ip].nt; it++, K++) {
         jur_curve_t const *cv = &pr->lv[ip].cv[it];
-        out->tval[K] = cv->t;
-        out->crv[K].a = cv->nu;
-        out->crv[K].b = (int)E;
-        for (int iu = 0; iu < cv->nu; iu++, E++) { out->ue[E].u = cv->u[iu]; out->ue[E].eps = cv->eps[iu]; }
+        out->crv[K].t = cv->t;
+        out->crv[K].nu = cv->nu;
+        out->crv[K].e0 = (int)E;
+        if (it > 0 && !(pr->lv[ip].cv[it - 1].t <= cv->t)) sorted = 0;
+        for (int iu = 0; iu < cv->nu; iu++, E++) {
+          out->ue[E].u = cv->u[iu];
+          out->ue[E].eps = cv->eps[iu];
+          if (iu > 0 && !(cv->u[iu - 1] <= cv->u[iu] && cv->eps[iu - 1] <= cv->eps[iu])) sorted = 0;
+        }
       }
     }
   }
+  out->sorted = sorted;
   return JUR_OK;
 }
 
 void jur_flat_free(jur_flat_t *f) {
-  free(f->pair); free(f->plev); free(f->lvl); free(f->tval); free(f->crv); free(f->ue);
+  free(f->pair); free(f->lvl); free(f->crv); free(f->ue);
   memset(f, 0, sizeof *f);
 }

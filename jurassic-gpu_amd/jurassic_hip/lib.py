@@ -45,6 +45,7 @@ def lib():
         L.jur_model_workspace_bytes.argtypes = [C.c_void_p]
         L.jur_model_chunk_rays.argtypes = [C.c_void_p]
         L.jur_model_set_chunk_rays.argtypes = [C.c_void_p, C.c_int]
+        L.jur_model_set_sort_rays.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_last_kernel_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
         L.jur_abi_sizes.argtypes = [C.POINTER(C.c_size_t)]
@@ -124,6 +125,9 @@ class Model:
 
     def set_chunk_rays(self, n):
         _chk(lib().jur_model_set_chunk_rays(self.h, n))
+
+    def set_sort_rays(self, on):
+        _chk(lib().jur_model_set_sort_rays(self.h, int(on)))
 
     def formod_host(self, geom, rad_in=None):
         """geom: (nr, 7).  -> dict(rad, tau, tp (nr,3), np)."""
