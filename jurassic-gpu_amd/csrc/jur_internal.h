@@ -56,7 +56,7 @@ typedef struct {
   int pad2;
   /* atmosphere, compact SoA of atm_np points */
   int atm_np;
-  int pad;
+  int atm_sorted;               /* time stamps non-decreasing and z strictly monotone inside every slice */
   double const *atm_time, *atm_z, *atm_lon, *atm_lat, *atm_p, *atm_t;
   double const *atm_q;          /* [ng][atm_np] */
   double const *atm_k;          /* [nw][atm_np] */
@@ -87,7 +87,8 @@ int jurk_launch_integrate(jur_view_t const *v, jur_chunk_t const *c, void *strea
 /* order rays by their geometric tangent altitude: fills order[nr]; `tmp` is a
  * device scratch of jurk_sort_tmp_bytes(nr) bytes */
 long jurk_sort_tmp_bytes(long nr);
-int jurk_sort_rays(long nr, double const *d_geom, int *d_order, void *tmp, long tmp_bytes, void *stream);
+int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, double const *d_geom, int *d_order, void *tmp,
+                   long tmp_bytes, void *stream);
 
 /* host tables (jur_tables.c) */
 typedef struct {

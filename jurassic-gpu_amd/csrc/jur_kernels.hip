@@ -89,9 +89,27 @@ __device__ __forceinline__ void geo2cart(double alt, double lon, double lat, dou
 
 __device__ __forceinline__ double refractivity(double p, double t) { return 7.753e-05 * p / t; }
 
-// pressure and temperature of the profile slice [i0, i0+n) at altitude z0 (jr_common.h:549-555)
-__device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, double z0, double &p, double &t) {
-  int const ip = i0 + locate_axis(v.atm_z + i0, n, z0);
+// Same bracket as locate_axis for a sorted axis, found by walking from a guess (the previous
+// point's bracket: altitude changes by <= RAYDZ per step).  dir > 0 ascending, < 0 descending.
+__device__ __forceinline__ int locate_axis_from(double const *__restrict__ xx, int n, double x, int dir, int g) {
+  int i = min(max(g, 0), n - 2);
+  if (dir > 0) {
+    while (i > 0 && xx[i] > x) --i;
+    while (i < n - 2 && !(xx[i + 1] > x)) ++i;
+  } else {
+    while (i > 0 && xx[i] <= x) --i;
+    while (i < n - 2 && !(xx[i + 1] <= x)) ++i;
+  }
+  return i;
+}
+
+// pressure and temperature of the profile slice [i0, i0+n) at altitude z0 (jr_common.h:549-555);
+// `hint` carries the bracket from call to call (dir == 0: exact bisection, axis not sorted)
+__device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, double z0, double &p, double &t, int dir,
+                                         int &hint) {
+  int const loc = dir ? locate_axis_from(v.atm_z + i0, n, z0, dir, hint) : locate_axis(v.atm_z + i0, n, z0);
+  hint = loc;
+  int const ip = i0 + loc;
   double const za = v.atm_z[ip], zb = v.atm_z[ip + 1];
   p = eip(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0);
   t = lip(za, v.atm_t[ip], zb, v.atm_t[ip + 1], z0);
@@ -176,6 +194,10 @@ __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t
     double lz2 = 0, llon2 = 0, llat2 = 0, lds2 = 0;         // point low_idx+1
     double last_z = 0, last_lon = 0, last_lat = 0;
 
+    // altitude brackets are resumed from the previous point when the slice's axis is strictly monotone
+    int const zdir = (v.atm_sorted && atmn >= 2) ? ((v.atm_z[atm0] < v.atm_z[atm0 + 1]) ? 1 : -1) : 0;
+    int zhint = (zdir > 0) ? atmn - 2 : 0, rhint = zhint;   // rays usually enter at the top
+
     int stop = 0;
     for (; np < NLOS; ++np) {
       double ds = v.rayds;
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t
       }
 
       double p, t;
-      int const ia = intpol_pt(v, atm0, atmn, z, p, t);
+      int const ia = intpol_pt(v, atm0, atmn, z, p, t, zdir, zhint);
       {  // remaining quantities on the same bracket (jr_common.h:557-567)
         double const za = v.atm_z[ia], zb = v.atm_z[ia + 1];
         for (int ig = 0; ig < v.ng; ig++) {
@@ -246,13 +268,13 @@ __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t
         double xh[3], zz, llon, llat, pp, tt;
         for (int i = 0; i < 3; i++) xh[i] = x[i] + 0.5 * ds * ex0[i];
         cart2geo(xh, zz, llon, llat);
-        intpol_pt(v, atm0, atmn, zz, pp, tt);
+        intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
         double const n2 = refractivity(pp, tt);
         for (int i = 0; i < 3; i++) {
           double const h = 0.02;
           xh[i] += h;
           cart2geo(xh, zz, llon, llat);
-          intpol_pt(v, atm0, atmn, zz, pp, tt);
+          intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
           ngr[i] = (refractivity(pp, tt) - n2) / h;
           xh[i] -= h;
         }
@@ -336,13 +358,22 @@ __device__ __forceinline__ int bisect_curve(Ue const *__restrict__ e, int n, dou
   return ilo;
 }
 
+struct __attribute__((aligned(8))) Ue2 { Ue a, b; };
+__device__ __forceinline__ void load_pair(Ue const *__restrict__ e, int i, Ue &a, Ue &b) {
+  Ue2 const ab = *reinterpret_cast<Ue2 const *>(e + i);   // entries i and i+1 are adjacent: one 16-byte load
+  a = ab.a; b = ab.b;
+}
+
 // WARM: move bracket i (entries a = e[i], b = e[i+1] already loaded) to the one that holds x:
-// key(e[i]) <= x < key(e[i+1]), clamped to [0, n-2].  Gallop, then bisect inside the gap.
+// key(e[i]) <= x < key(e[i+1]), clamped to [0, n-2].  One step is the common case; otherwise
+// gallop, then bisect inside the gap.
 template <bool ON_EPS>
 __device__ __forceinline__ void seek_curve(Ue const *__restrict__ e, int n, double x, int &i, Ue &a, Ue &b) {
   if (x >= ukey<ON_EPS>(b)) {
     if (i >= n - 2) return;
-    int lo = i + 1, hi, step = 1;
+    Ue const c = e[i + 2];
+    if (i + 2 >= n - 1 || ukey<ON_EPS>(c) > x) { ++i; a = b; b = c; return; }
+    int lo = i + 2, hi, step = 2;
     for (;;) {
       hi = lo + step;
       if (hi >= n - 1) { hi = n - 1; break; }
@@ -354,10 +385,13 @@ __device__ __forceinline__ void seek_curve(Ue const *__restrict__ e, int n, doub
       int const mid = (lo + hi) >> 1;
       if (ukey<ON_EPS>(e[mid]) > x) hi = mid; else lo = mid;
     }
-    i = lo; a = e[lo]; b = e[lo + 1];
+    i = lo;
+    load_pair(e, i, a, b);
   } else if (x < ukey<ON_EPS>(a)) {
     if (i <= 0) return;
-    int hi = i, lo, step = 1;
+    Ue const c = e[i - 1];
+    if (i - 1 <= 0 || ukey<ON_EPS>(c) <= x) { --i; b = a; a = c; return; }
+    int hi = i - 1, lo, step = 2;
     for (;;) {
       lo = hi - step;
       if (lo <= 0) { lo = 0; break; }
@@ -369,7 +403,8 @@ __device__ __forceinline__ void seek_curve(Ue const *__restrict__ e, int n, doub
       int const mid = (lo + hi) >> 1;
       if (ukey<ON_EPS>(e[mid]) > x) hi = mid; else lo = mid;
     }
-    i = lo; a = e[lo]; b = e[lo + 1];
+    i = lo;
+    load_pair(e, i, a, b);
   }
 }
 
@@ -381,12 +416,12 @@ __device__ __forceinline__ double corner_eps(Ue const *__restrict__ e, int n, do
   int i;
   if (WARM) {
     i = min(idx, n - 2);
-    a = e[i]; b = e[i + 1];
+    load_pair(e, i, a, b);
     seek_curve<true>(e, n, eps, i, a, b);
     idx = i;
   } else {
     i = bisect_curve<true>(e, n, eps);
-    a = e[i]; b = e[i + 1];
+    load_pair(e, i, a, b);
   }
   double const uc = lip((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps);
   double const x = uc + u;
@@ -394,7 +429,7 @@ __device__ __forceinline__ double corner_eps(Ue const *__restrict__ e, int n, do
     seek_curve<false>(e, n, x, i, a, b);
   } else {
     i = bisect_curve<false>(e, n, x);
-    a = e[i]; b = e[i + 1];
+    load_pair(e, i, a, b);
   }
   return c01(lip((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, x));
 }
@@ -516,14 +551,20 @@ __device__ __forceinline__ double planck_src(double const *__restrict__ sr, doub
 }
 
 // ---------------------------------------------------------------------------------------
-// along-path integration, one lane per (ray, channel)
+// along-path integration: one lane per ray, one channel per workgroup (blockIdx.y).  The 64
+// lanes of a wavefront are neighbouring rays of the sorted order looking into the SAME
+// (gas, channel) table, so their gathers fall into few cache lines; everything that depends
+// on the channel only is wave-uniform and lives in scalar registers.
 // ---------------------------------------------------------------------------------------
+#ifndef JUR_INT_WAVES
+#define JUR_INT_WAVES 3   /* measured: 3 waves/SIMD (168 VGPRs, 84 B scratch) beats 2 and 4 */
+#endif
 template <int NGT, bool WARM>
-__global__ __launch_bounds__(256) void jur_integrate_kernel(jur_view_t v, jur_chunk_t c) {
-  long const lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256, JUR_INT_WAVES) void jur_integrate_kernel(jur_view_t v, jur_chunk_t c) {
+  int const r = blockIdx.x * blockDim.x + threadIdx.x;   // slot in the chunk
   int const nd = v.nd;
-  if (lane >= (long)c.n * nd) return;
-  int const r = (int)(lane / nd), d = (int)(lane - (long)r * nd);   // slot, channel
+  int const d = blockIdx.y;                              // channel, uniform
+  if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
   size_t const R = (size_t)c.stride;
   size_t const fs = (size_t)NLOS * R;
@@ -544,28 +585,16 @@ __global__ __launch_bounds__(256) void jur_integrate_kernel(jur_view_t v, jur_ch
   for (int g = 0; g < NGT; g++) { tau_path[g] = 1.0; br[g] = 0; ia[g] = 0; ib[g] = 0; }
 
   int const np = c.np[r];
-  // segment state of the current point; the next point's is fetched while this one is worked on
-  double p = 0, t = 0, ds = 0, kx = 0, qh = 0, ug[NGT];
-  auto fetch = [&](int ip, double &p_, double &t_, double &ds_, double &k_, double &q_, double (&u_)[NGT]) {
-    size_t const o = (size_t)ip * R;
-    p_ = los[JUR_F_P * fs + o];
-    t_ = los[JUR_F_T * fs + o];
-    ds_ = los[JUR_F_DS * fs + o];
-    k_ = los[f_k * fs + o];
-    if (do_h2o) q_ = los[JUR_F_QH2O * fs + o];
-#pragma unroll
-    for (int g = 0; g < NGT; g++)
-      if (g < ng) u_[g] = los[(f_u + g) * fs + o];
-  };
-#pragma unroll
-  for (int g = 0; g < NGT; g++) ug[g] = 0;
-  if (np > 0) fetch(0, p, t, ds, kx, qh, ug);
-
   for (int ip = 0; ip < np; ++ip) {
-    double pn = 0, tn = 0, dsn = 0, kn = 0, qn = 0, un[NGT];
+    // segment state: coalesced over the rays of the wavefront.  (Fetching the next point's state
+    // ahead of time was measured slower: the extra registers cost a wave per SIMD.)
+    size_t const o = (size_t)ip * R;
+    double const p = los[JUR_F_P * fs + o], t = los[JUR_F_T * fs + o], ds = los[JUR_F_DS * fs + o];
+    double const kx = los[f_k * fs + o];
+    double const qh = do_h2o ? los[JUR_F_QH2O * fs + o] : 0.;
+    double ug[NGT];
 #pragma unroll
-    for (int g = 0; g < NGT; g++) un[g] = 0;
-    if (ip + 1 < np) fetch(ip + 1, pn, tn, dsn, kn, qn, un);
+    for (int g = 0; g < NGT; g++) ug[g] = (g < ng) ? los[(f_u + g) * fs + o] : 0.;
 
     // extinction and continua (jr_continua_core.mv4g.h:1-14)
     double beta_ds = kx * ds;
@@ -601,9 +630,6 @@ __global__ __launch_bounds__(256) void jur_integrate_kernel(jur_view_t v, jur_ch
       rad += src * eps * tau;
       tau *= (1. - eps);
     }
-    p = pn; t = tn; ds = dsn; kx = kn; qh = qn;
-#pragma unroll
-    for (int g = 0; g < NGT; g++) ug[g] = un[g];
   }
 
   double const tsurf = c.tsurf[r];
@@ -615,10 +641,13 @@ __global__ __launch_bounds__(256) void jur_integrate_kernel(jur_view_t v, jur_ch
 }
 
 // ---------------------------------------------------------------------------------------
-// ray ordering key: altitude of the straight line's closest approach to the Earth's centre
+// ray ordering key: altitude of the straight line's closest approach to the Earth's centre;
+// optionally grouped by the atmosphere slice the ray uses (neighbouring lanes then walk through
+// the same profile, i.e. the same table brackets)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void jur_raykey_kernel(long nr, double const *__restrict__ geom,
-                                                         float *__restrict__ key, int *__restrict__ id) {
+                                                         double const *__restrict__ atm_time, int atm_np, int by_profile,
+                                                         unsigned long long *__restrict__ key, int *__restrict__ id) {
   long const r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nr) return;
   double xo[3], xv[3], e[3];
@@ -632,7 +661,19 @@ __global__ __launch_bounds__(256) void jur_raykey_kernel(long nr, double const *
     for (int i = 0; i < 3; i++) s -= xo[i] * e[i] / n;
     if (s > 0) h = sqrt(fmax(xo[0] * xo[0] + xo[1] * xo[1] + xo[2] * xo[2] - s * s, 0.)) - JUR_RE;
   }
-  key[r] = (float)h;
+  unsigned const fb = __float_as_uint((float)h);
+  unsigned const ord = fb ^ ((fb >> 31) ? 0xffffffffu : 0x80000000u);   // unsigned order == float order
+  unsigned long long slice = 0;
+  if (by_profile) {  // first point of the profile slice with this ray's time stamp (jr_common.h:130-140)
+    double const time = geom[r];
+    int lo = 0, hi = atm_np - 1;
+    while (hi > lo + 1) {
+      int const i = (lo + hi) / 2;
+      if (atm_time[i] < time) lo = i; else hi = i;
+    }
+    slice = (unsigned long long)((0 == lo) ? lo : hi);
+  }
+  key[r] = (slice << 32) | ord;
   id[r] = (int)r;
 }
 
@@ -649,13 +690,12 @@ extern "C" int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void
 extern "C" int jurk_launch_integrate(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
   if (c->n <= 0) return 0;
   int const block = 256;
-  long const lanes = (long)c->n * v->nd;
-  int const grid = (int)((lanes + block - 1) / block);
+  dim3 const grid((unsigned)((c->n + block - 1) / block), (unsigned)v->nd);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(N)                                                                                         \
   do {                                                                                                    \
-    if (v->sorted_tables) hipLaunchKernelGGL((jur_integrate_kernel<N, true>), dim3(grid), dim3(block), 0, s, *v, *c); \
-    else hipLaunchKernelGGL((jur_integrate_kernel<N, false>), dim3(grid), dim3(block), 0, s, *v, *c);    \
+    if (v->sorted_tables) hipLaunchKernelGGL((jur_integrate_kernel<N, true>), grid, dim3(block), 0, s, *v, *c); \
+    else hipLaunchKernelGGL((jur_integrate_kernel<N, false>), grid, dim3(block), 0, s, *v, *c);          \
   } while (0)
   if (v->ng <= 1) LAUNCH(1);
   else if (v->ng <= 2) LAUNCH(2);
@@ -675,25 +715,27 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" long jurk_sort_tmp_bytes(long nr) {
   size_t cub = 0;
-  if (hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (float const *)nullptr, (float *)nullptr, (int const *)nullptr,
-                                         (int *)nullptr, (int)nr) != hipSuccess)
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (unsigned long long const *)nullptr, (unsigned long long *)nullptr,
+                                         (int const *)nullptr, (int *)nullptr, (int)nr) != hipSuccess)
     cub = 64 * (size_t)nr + (1 << 20);
-  return (long)(3 * align_up(sizeof(float) * (size_t)nr) + align_up(cub) + 256);
+  return (long)(2 * align_up(8 * (size_t)nr) + align_up(4 * (size_t)nr) + align_up(cub) + 256);
 }
 
-extern "C" int jurk_sort_rays(long nr, double const *d_geom, int *d_order, void *tmp, long tmp_bytes, void *stream) {
+extern "C" int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, double const *d_geom, int *d_order, void *tmp,
+                              long tmp_bytes, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  size_t const seg = align_up(sizeof(float) * (size_t)nr);
+  size_t const seg8 = align_up(8 * (size_t)nr), seg4 = align_up(4 * (size_t)nr);
   char *base = (char *)tmp;
-  float *key_in = (float *)base, *key_out = (float *)(base + seg);
-  int *id_in = (int *)(base + 2 * seg);
-  void *cub_tmp = base + 3 * seg;
-  size_t cub_bytes = (size_t)tmp_bytes - 3 * seg;
+  unsigned long long *key_in = (unsigned long long *)base, *key_out = (unsigned long long *)(base + seg8);
+  int *id_in = (int *)(base + 2 * seg8);
+  void *cub_tmp = base + 2 * seg8 + seg4;
+  size_t cub_bytes = (size_t)tmp_bytes - 2 * seg8 - seg4;
   int const block = 256;
-  hipLaunchKernelGGL(jur_raykey_kernel, dim3((unsigned)((nr + block - 1) / block)), dim3(block), 0, s, nr, d_geom, key_in,
-                     id_in);
+  hipLaunchKernelGGL(jur_raykey_kernel, dim3((unsigned)((nr + block - 1) / block)), dim3(block), 0, s, nr, d_geom,
+                     v->atm_time, v->atm_np, by_profile, key_in, id_in);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, key_in, key_out, id_in, d_order, (int)nr, 0, 32, s);
+  e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, key_in, key_out, id_in, d_order, (int)nr, 0,
+                                         by_profile ? 64 : 32, s);
   return (int)e;
 }

@@ -32,6 +32,7 @@ struct jur_model {
   void *d_chan, *d_sr, *d_pair, *d_lvl, *d_crv, *d_ue;
   void *d_atm;                  /* one slab for the compact atmosphere           */
   int atm_cap;
+  int atm_slices;               /* distinct time stamps in the atmosphere        */
   /* per-call workspace */
   int chunk_rays;               /* R                                             */
   int nfield;
@@ -256,6 +257,19 @@ int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
   if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
   free(h);
   if (e != hipSuccess) { jur_set_error("atm upload failed: %s", hipGetErrorString(e)); return JUR_EHIP; }
+  m->atm_slices = 1;
+  v->atm_sorted = 1;
+  for (int i = 1, dir = 0; i < n; i++) {
+    if (atm->time[i] != atm->time[i - 1]) {
+      m->atm_slices++;
+      if (atm->time[i] < atm->time[i - 1]) v->atm_sorted = 0;
+      dir = 0;
+      continue;
+    }
+    int const d = (atm->z[i] > atm->z[i - 1]) - (atm->z[i] < atm->z[i - 1]);
+    if (d == 0 || (dir != 0 && d != dir)) v->atm_sorted = 0;
+    dir = d;
+  }
   double const *d = (double const *)m->d_atm;
   v->atm_np = n;
   v->atm_time = d; v->atm_z = d + (size_t)n; v->atm_lon = d + 2 * (size_t)n; v->atm_lat = d + 3 * (size_t)n;
@@ -349,7 +363,9 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
       HIPCHK(hipMalloc(&m->d_sort_tmp, (size_t)need));
       m->order_cap = nr; m->sort_tmp_bytes = need;
     }
-    int const e = jurk_sort_rays(nr, d_geom, m->d_order, m->d_sort_tmp, m->sort_tmp_bytes, s);
+    /* group by atmosphere slice when every slice is used by many rays */
+    int const by_profile = m->atm_slices > 1 && nr >= 1024L * m->atm_slices;
+    int const e = jurk_sort_rays(&m->view, by_profile, nr, d_geom, m->d_order, m->d_sort_tmp, m->sort_tmp_bytes, s);
     if (e) { jur_set_error("ray sort failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
     order = m->d_order;
   }

@@ -9,7 +9,7 @@ import numpy as np
 from . import abi
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(PKG, "libjurassic_hip.so")
+SO = os.environ.get("JURASSIC_HIP_SO", os.path.join(PKG, "libjurassic_hip.so"))   # override: A/B builds only
 _lib = None
 dp = C.POINTER(C.c_double)
 
