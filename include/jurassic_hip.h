@@ -102,12 +102,15 @@ int  jur_model_chunk_rays(jur_model_t const *m);
  * geometric tangent altitude (default on; results do not depend on it). */
 int  jur_model_set_chunk_rays(jur_model_t *m, int rays);
 int  jur_model_set_sort_rays(jur_model_t *m, int on);
+/* Upper bound of the per-call device workspace (LOS state + per-segment gas
+ * transmittances); the rays-per-chunk shrink to fit.  Default 24 GiB. */
+int  jur_model_set_workspace_budget(jur_model_t *m, long bytes);
 
-/* Duration in ms of the most recent launch of each kernel on this model,
- * measured with HIP events on the launch stream when profiling is enabled
- * (jur_model_enable_timing(m, 1)); [0]=trace [1]=integrate. */
+/* Summed duration in ms and launch count of each kernel since the last query,
+ * measured with HIP events on the launch stream while timing is enabled:
+ * [0] jur_trace_kernel, [1] jur_ega_kernel, [2] jur_combine_kernel. */
 int  jur_model_enable_timing(jur_model_t *m, int on);
-int  jur_model_last_kernel_ms(jur_model_t *m, double out_ms[2], long out_launches[2]);
+int  jur_model_last_kernel_ms(jur_model_t *m, double out_ms[3], long out_launches[3]);
 
 #ifdef __cplusplus
 }

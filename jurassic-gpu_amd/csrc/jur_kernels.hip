@@ -641,6 +641,91 @@ __global__ __launch_bounds__(256, JUR_INT_WAVES) void jur_integrate_kernel(jur_v
 }
 
 // ---------------------------------------------------------------------------------------
+// split form of the along-path integration (used when the workspace can hold the segment
+// transmittances): the emissivity-growth recurrence of every (ray, channel, gas) triple is an
+// independent sequential chain, so it gets its own lane -- ng x more lanes, a third of the
+// registers, 6+ waves per SIMD to hide the dependent table loads -- and hands its per-segment
+// transmittance to the combine kernel through HBM ([pair][point][ray], ray fastest).
+//
+// jur_ega_kernel: one lane per ray, one (channel, gas) pair per workgroup.  Workgroups that
+// share a block of rays are made consecutive on one XCD (they re-read the same p, T, u lines
+// from that XCD's L2): b -> xcd = b % 8, s = b / 8, ray block = (s / npair) * 8 + xcd,
+// pair = s % npair.  Placement only affects speed.
+// ---------------------------------------------------------------------------------------
+template <bool WARM>
+__global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
+  int const npair = v.nd * v.ng;
+  int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
+  int const rb = (sq / npair) * 8 + xcd, pr = sq - (sq / npair) * npair;   // ray block, pair: uniform
+  if (rb >= nrb) return;
+  int const d = pr / v.ng, g = pr - d * v.ng;
+  int const r = rb * blockDim.x + threadIdx.x;
+  if (r >= c.n) return;
+  int const pair_idx = g * v.nd + d;
+  if (v.pair[pair_idx].a < 2) return;            // no table: transmittance 1, the combine kernel knows
+  size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
+  double const *const los = c.los + r;
+  double *const out = c.eps + (size_t)pr * fs + r;
+  int const f_u = JUR_F_K + v.nw + g;
+  int const np = c.np[r];
+  double tau_path = 1.0;
+  unsigned br = 0, ia = 0, ib = 0;
+  for (int ip = 0; ip < np; ++ip) {
+    size_t const o = (size_t)ip * R;
+    double const p = los[JUR_F_P * fs + o], t = los[JUR_F_T * fs + o], u = los[f_u * fs + o];
+    double const eps = ega_eps<WARM>(v, pair_idx, tau_path, t, u, p, br, ia, ib);
+    tau_path *= eps;
+    out[o] = eps;
+  }
+}
+
+// jur_combine_kernel: one lane per ray, one channel per workgroup: continua, product of the gas
+// transmittances in the reference's order, Planck source, radiance update, epilogue.
+__global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chunk_t c) {
+  int const r = blockIdx.x * blockDim.x + threadIdx.x;
+  int const nd = v.nd, ng = v.ng;
+  int const d = blockIdx.y;
+  if (r >= c.n) return;
+  long const ray = c.order ? (long)c.order[r] : c.first + r;
+  size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
+  double const *const los = c.los + r;
+  double const *const epsb = c.eps + (size_t)d * ng * fs + r;
+  jur_chan_t const ch = v.chan[d];
+  double const *const sr = v.sr + (size_t)d * TBLNS;
+  int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
+  bool const do_co2 = (v.fourbit & 8) && ch.co2_on, do_h2o = (v.fourbit & 4) && ch.h2o_on,
+             do_n2 = (v.fourbit & 2) && ch.n2_on, do_o2 = (v.fourbit & 1) && ch.o2_on;
+  size_t const oidx = (size_t)ray * nd + d;
+  bool const masked = !isfinite(c.rad[oidx]);
+  double rad = 0.0, tau = 1.0;
+  int const np = c.np[r];
+  for (int ip = 0; ip < np; ++ip) {
+    size_t const o = (size_t)ip * R;
+    double const p = los[JUR_F_P * fs + o], t = los[JUR_F_T * fs + o], ds = los[JUR_F_DS * fs + o];
+    double beta_ds = los[f_k * fs + o] * ds;
+    if (do_co2) beta_ds += ctm_co2(ch, p, t, los[(f_u + v.ig_co2) * fs + o]);
+    if (do_h2o) beta_ds += ctm_h2o(ch, p, t, los[JUR_F_QH2O * fs + o], los[(f_u + v.ig_h2o) * fs + o]);
+    if (do_n2) beta_ds += ctm_n2(ch, p, t) * ds;
+    if (do_o2) beta_ds += ctm_o2(ch, p, t) * ds;
+    double tau_gas = 1.0;
+    for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
+      if (v.pair[g * nd + d].a >= 2) tau_gas *= epsb[(size_t)g * fs + o];
+    double const src = planck_src(sr, t);
+    if (tau_gas > 1e-50) {  // jr_common.h:293-300
+      double const eps = 1. - tau_gas * exp(-beta_ds);
+      rad += src * eps * tau;
+      tau *= (1. - eps);
+    }
+  }
+  double const tsurf = c.tsurf[r];
+  if (tsurf > 0.) rad += planck_src(sr, tsurf) * tau;
+  if (v.write_bbt) rad = JUR_C2 * ch.nu / log1p((JUR_C1 * ch.nu * ch.nu * ch.nu) / rad);
+  if (masked) rad = __builtin_nan("");
+  c.rad[oidx] = rad;
+  c.tau[oidx] = tau;
+}
+
+// ---------------------------------------------------------------------------------------
 // ray ordering key: altitude of the straight line's closest approach to the Earth's centre;
 // optionally grouped by the atmosphere slice the ray uses (neighbouring lanes then walk through
 // the same profile, i.e. the same table brackets)
@@ -708,6 +793,25 @@ extern "C" int jurk_launch_integrate(jur_view_t const *v, jur_chunk_t const *c, 
   else if (v->ng <= 16) LAUNCH(16);
   else LAUNCH(JUR_NG);
 #undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
+  if (c->n <= 0 || v->ng <= 0) return 0;
+  int const block = 256;
+  int const nrb = (c->n + block - 1) / block, npair = v->nd * v->ng;
+  unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * npair);
+  hipStream_t s = (hipStream_t)stream;
+  if (v->sorted_tables) hipLaunchKernelGGL(jur_ega_kernel<true>, dim3(grid), dim3(block), 0, s, *v, *c, nrb);
+  else hipLaunchKernelGGL(jur_ega_kernel<false>, dim3(grid), dim3(block), 0, s, *v, *c, nrb);
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
+  if (c->n <= 0) return 0;
+  int const block = 256;
+  dim3 const grid((unsigned)((c->n + block - 1) / block), (unsigned)v->nd);
+  hipLaunchKernelGGL(jur_combine_kernel, grid, dim3(block), 0, (hipStream_t)stream, *v, *c);
   return (int)hipGetLastError();
 }
 

@@ -37,6 +37,10 @@ struct jur_model {
   int chunk_rays;               /* R                                             */
   int nfield;
   double *d_los;
+  double *d_eps;                /* split path: segment transmittances            */
+  int split;                    /* 1: ega + combine kernels, 0: fused integrate  */
+  long ws_budget;               /* bytes of workspace the model may hold         */
+  long ws_rays;                 /* R the workspace is laid out for               */
   int *d_np;
   double *d_tsurf;
   int *d_status;
@@ -53,7 +57,7 @@ struct jur_model {
   hipStream_t stream;
   /* timing */
   int timing;
-  hipEvent_t *evpool;           /* 3 events per timed chunk                      */
+  hipEvent_t *evpool;           /* 4 events per timed chunk                      */
   int ntimed;
 };
 
@@ -150,6 +154,8 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   m->nfield = JUR_F_K + v->nw + v->ng;
   m->chunk_rays = 131072;
   m->sort_rays = 1;
+  m->split = (getenv("JUR_FUSED") && atoi(getenv("JUR_FUSED"))) ? 0 : 1;   /* A/B switch */
+  m->ws_budget = 24L << 30;
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { jur_set_error("hipStreamCreate failed"); jur_model_destroy(m); return JUR_EHIP; }
   if ((rc = upload((void **)&m->d_status, NULL, sizeof(int)))) { jur_model_destroy(m); return rc; }
   HIPCHK(hipMemset(m->d_status, 0, sizeof(int)));
@@ -178,12 +184,12 @@ void jur_model_destroy(jur_model_t *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_lvl, m->d_crv, m->d_ue, m->d_atm, m->d_order, m->d_sort_tmp,
-                  m->d_los, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np};
+                  m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
     if (ptrs[i]) (void)hipFree(ptrs[i]);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   if (m->evpool) {
-    for (int i = 0; i < 3 * JUR_MAX_TIMED; i++) (void)hipEventDestroy(m->evpool[i]);
+    for (int i = 0; i < 4 * JUR_MAX_TIMED; i++) (void)hipEventDestroy(m->evpool[i]);
     free(m->evpool);
   }
   free(m->ctl);
@@ -280,19 +286,26 @@ int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
 
 /* ---- workspace --------------------------------------------------------------- */
 static int ensure_workspace(jur_model_t *m, long nr) {
+  /* bytes per ray: LOS fields, plus one double per (channel, gas, point) on the split path */
+  long const per_ray_los = (long)sizeof(double) * m->nfield * JUR_NLOS;
+  long const per_ray_eps = m->split ? (long)sizeof(double) * m->view.nd * m->view.ng * JUR_NLOS : 0;
   long R = m->chunk_rays;
+  long const fit = m->ws_budget / (per_ray_los + per_ray_eps);
+  if (R > fit) R = fit / 64 * 64;
   if (nr < R) R = (nr + 63) / 64 * 64;
   if (R < 64) R = 64;
-  long const need = (long)sizeof(double) * m->nfield * JUR_NLOS * R;
-  if (need > m->los_bytes) {
+  if (R > m->ws_rays) {
     if (m->d_los) (void)hipFree(m->d_los);
+    if (m->d_eps) (void)hipFree(m->d_eps);
     if (m->d_np) (void)hipFree(m->d_np);
     if (m->d_tsurf) (void)hipFree(m->d_tsurf);
-    m->d_los = NULL; m->d_np = NULL; m->d_tsurf = NULL; m->los_bytes = 0;
-    HIPCHK(hipMalloc((void **)&m->d_los, need));
+    m->d_los = NULL; m->d_eps = NULL; m->d_np = NULL; m->d_tsurf = NULL; m->los_bytes = 0; m->ws_rays = 0;
+    HIPCHK(hipMalloc((void **)&m->d_los, (size_t)per_ray_los * R));
+    if (per_ray_eps) HIPCHK(hipMalloc((void **)&m->d_eps, (size_t)per_ray_eps * R));
     HIPCHK(hipMalloc((void **)&m->d_np, sizeof(int) * R));
     HIPCHK(hipMalloc((void **)&m->d_tsurf, sizeof(double) * R));
-    m->los_bytes = need;
+    m->los_bytes = (per_ray_los + per_ray_eps) * R;
+    m->ws_rays = R;
   }
   return JUR_OK;
 }
@@ -301,6 +314,12 @@ long jur_model_workspace_bytes(jur_model_t const *m) { return m->los_bytes; }
 int jur_model_chunk_rays(jur_model_t const *m) { return m->chunk_rays; }
 
 int jur_model_set_sort_rays(jur_model_t *m, int on) { m->sort_rays = on ? 1 : 0; return JUR_OK; }
+
+int jur_model_set_workspace_budget(jur_model_t *m, long bytes) {
+  if (bytes < (64L << 20)) { jur_set_error("workspace budget below 64 MiB"); return JUR_EINVAL; }
+  m->ws_budget = bytes;
+  return JUR_OK;
+}
 
 int jur_model_set_chunk_rays(jur_model_t *m, int rays) {
   if (rays < 64 || rays > (1 << 22)) { jur_set_error("chunk_rays must be in 64..4194304"); return JUR_EINVAL; }
@@ -311,9 +330,9 @@ int jur_model_set_chunk_rays(jur_model_t *m, int rays) {
 int jur_model_enable_timing(jur_model_t *m, int on) {
   HIPCHK(hipSetDevice(m->device));
   if (on && !m->evpool) {
-    m->evpool = (hipEvent_t *)calloc(3 * JUR_MAX_TIMED, sizeof(hipEvent_t));
+    m->evpool = (hipEvent_t *)calloc(4 * JUR_MAX_TIMED, sizeof(hipEvent_t));
     if (!m->evpool) return JUR_ENOMEM;
-    for (int i = 0; i < 3 * JUR_MAX_TIMED; i++) HIPCHK(hipEventCreate(&m->evpool[i]));
+    for (int i = 0; i < 4 * JUR_MAX_TIMED; i++) HIPCHK(hipEventCreate(&m->evpool[i]));
   }
   m->timing = on;
   m->ntimed = 0;
@@ -321,19 +340,21 @@ int jur_model_enable_timing(jur_model_t *m, int on) {
 }
 
 /* Sums the event-bracketed durations of the launches recorded since the last
- * call (at most JUR_MAX_TIMED chunks), then starts over. */
-int jur_model_last_kernel_ms(jur_model_t *m, double out_ms[2], long out_launches[2]) {
-  out_ms[0] = out_ms[1] = 0;
-  out_launches[0] = out_launches[1] = 0;
+ * call (at most JUR_MAX_TIMED chunks), then starts over.
+ * [0] trace, [1] ega (split path) or fused integrate, [2] combine (split path). */
+int jur_model_last_kernel_ms(jur_model_t *m, double out_ms[3], long out_launches[3]) {
+  for (int k = 0; k < 3; k++) { out_ms[k] = 0; out_launches[k] = 0; }
   if (!m->evpool) return JUR_OK;
   HIPCHK(hipSetDevice(m->device));
   for (int i = 0; i < m->ntimed; i++) {
-    float ms = 0;
-    HIPCHK(hipEventSynchronize(m->evpool[3 * i + 2]));
-    HIPCHK(hipEventElapsedTime(&ms, m->evpool[3 * i], m->evpool[3 * i + 1]));
-    out_ms[0] += ms; out_launches[0]++;
-    HIPCHK(hipEventElapsedTime(&ms, m->evpool[3 * i + 1], m->evpool[3 * i + 2]));
-    out_ms[1] += ms; out_launches[1]++;
+    hipEvent_t *ev = m->evpool + 4 * i;
+    HIPCHK(hipEventSynchronize(ev[3]));
+    for (int k = 0; k < 3; k++) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+      if (k == 2 && !m->split) continue;
+      out_ms[k] += ms; out_launches[k]++;
+    }
   }
   m->ntimed = 0;
   return JUR_OK;
@@ -349,7 +370,7 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
   int rc = ensure_workspace(m, nr);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  long const R = m->los_bytes / ((long)sizeof(double) * m->nfield * JUR_NLOS);
+  long const R = m->ws_rays;
   int const *order = NULL;
   if (m->sort_rays && nr > 64) {
     /* similar rays side by side: equal trip counts inside a wavefront and neighbouring
@@ -383,16 +404,26 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     c.np = m->d_np;
     c.tsurf = m->d_tsurf;
     c.los = m->d_los;
+    c.eps = m->d_eps;
     c.status = d_status ? d_status : m->d_status;
-    hipEvent_t *ev = (m->timing && m->ntimed < JUR_MAX_TIMED) ? m->evpool + 3 * m->ntimed : NULL;
+    hipEvent_t *ev = (m->timing && m->ntimed < JUR_MAX_TIMED) ? m->evpool + 4 * m->ntimed : NULL;
     if (ev) HIPCHK(hipEventRecord(ev[0], s));
     int e = jurk_launch_trace(&m->view, &c, s);
     if (e) { jur_set_error("trace kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
     if (ev) HIPCHK(hipEventRecord(ev[1], s));
-    e = jurk_launch_integrate(&m->view, &c, s);
-    if (e) { jur_set_error("integrate kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
+    if (m->split) {
+      e = jurk_launch_ega(&m->view, &c, s);
+      if (e) { jur_set_error("ega kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
+      if (ev) HIPCHK(hipEventRecord(ev[2], s));
+      e = jurk_launch_combine(&m->view, &c, s);
+      if (e) { jur_set_error("combine kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
+    } else {
+      e = jurk_launch_integrate(&m->view, &c, s);
+      if (e) { jur_set_error("integrate kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
+      if (ev) HIPCHK(hipEventRecord(ev[2], s));
+    }
     if (ev) {
-      HIPCHK(hipEventRecord(ev[2], s));
+      HIPCHK(hipEventRecord(ev[3], s));
       m->ntimed++;
     }
   }

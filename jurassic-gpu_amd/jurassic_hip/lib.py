@@ -46,6 +46,7 @@ def lib():
         L.jur_model_chunk_rays.argtypes = [C.c_void_p]
         L.jur_model_set_chunk_rays.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_set_sort_rays.argtypes = [C.c_void_p, C.c_int]
+        L.jur_model_set_workspace_budget.argtypes = [C.c_void_p, C.c_long]
         L.jur_model_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_last_kernel_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
         L.jur_abi_sizes.argtypes = [C.POINTER(C.c_size_t)]
@@ -129,6 +130,9 @@ class Model:
     def set_sort_rays(self, on):
         _chk(lib().jur_model_set_sort_rays(self.h, int(on)))
 
+    def set_workspace_budget(self, nbytes):
+        _chk(lib().jur_model_set_workspace_budget(self.h, nbytes))
+
     def formod_host(self, geom, rad_in=None):
         """geom: (nr, 7).  -> dict(rad, tau, tp (nr,3), np)."""
         g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
@@ -150,10 +154,11 @@ class Model:
         _chk(lib().jur_model_enable_timing(self.h, int(on)))
 
     def kernel_ms(self):
-        ms = (C.c_double * 2)()
-        n = (C.c_long * 2)()
+        ms = (C.c_double * 3)()
+        n = (C.c_long * 3)()
         _chk(lib().jur_model_last_kernel_ms(self.h, ms, n))
-        return dict(trace_ms=ms[0], integrate_ms=ms[1], trace_launches=n[0], integrate_launches=n[1])
+        return dict(trace_ms=ms[0], ega_ms=ms[1], combine_ms=ms[2], trace_launches=n[0], ega_launches=n[1],
+                    combine_launches=n[2])
 
     def workspace_bytes(self):
         return lib().jur_model_workspace_bytes(self.h)

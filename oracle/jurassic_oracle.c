@@ -798,10 +798,11 @@ static inline int Lprobe(int n) {                       /* ceil(log2(n-1)) probe
 
 double orc_algorithmic_bytes(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tb, long nr, double const *time,
                              double const *obsz, double const *obslon, double const *obslat, double const *vpz,
-                             double const *vplon, double const *vplat, long *nseg_out, double *trace_part) {
-  double total = 0, ttrace = 0;
+                             double const *vplon, double const *vplat, long *nseg_out, double *trace_part,
+                             double *ega_part) {
+  double total = 0, ttrace = 0, tega = 0;
   long nseg = 0;
-#pragma omp parallel reduction(+ : total, ttrace, nseg)
+#pragma omp parallel reduction(+ : total, ttrace, tega, nseg)
   {
     pos_t *los = (pos_t *)malloc(sizeof(pos_t) * NLOS);
 #pragma omp for schedule(dynamic, 16)
@@ -813,7 +814,7 @@ double orc_algorithmic_bytes(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tb, 
       locate_atm(atm, geom[0], &atmIdx, &atmNp);
       int const La = Lprobe(atmNp);
       double bytes = 80 + 24 * ctl->nd;                 /* B_io */
-      double tr = bytes;
+      double tr = bytes, eg = 0;
       for (int ip = 0; ip < np; ip++) {
         double b_atm = 16 * La + 16 * (3 + ctl->ng + ctl->nw);
         if (ctl->refrac && los[ip].z <= 60 && ip < np - 1) b_atm += 4 * (8 * La + 48);
@@ -829,16 +830,18 @@ double orc_algorithmic_bytes(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tb, 
             int const it0 = locate_t(tb, ig, ipr, n_t, los[ip].t, id);
             int const n_u = T_NU(tb, ig, ipr, it0, id);
             if (n_u < 2) continue;
-            bytes += 236 + 8 * Lprobe(n_p) + 16 * Lprobe(n_t) + 32 * Lprobe(n_u);
+            eg += 236 + 8 * Lprobe(n_p) + 16 * Lprobe(n_t) + 32 * Lprobe(n_u);
           }
       }
-      total += bytes;
+      total += bytes + eg;
       ttrace += tr;
+      tega += eg;
       nseg += np;
     }
     free(los);
   }
   if (nseg_out) *nseg_out = nseg;
   if (trace_part) *trace_part = ttrace;
+  if (ega_part) *ega_part = tega;
   return total;
 }

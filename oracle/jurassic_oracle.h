@@ -81,12 +81,14 @@ void orc_formod_rays(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tbl,
 /* Algorithmic bytes of the reference algorithm for these rays
  * (A_ray summed over rays).  Also returns the number of
  * LOS segments in *nseg and, in *trace_part, the share that belongs to ray
- * tracing (B_io + sum of B_atm); the rest belongs to the along-path integration. */
+ * tracing (B_io + sum of B_atm) and, in *ega_part, the emissivity-growth look-ups
+ * (sum of B_ega); the rest (B_seg, B_src) belongs to the per-segment combine step. */
 double orc_algorithmic_bytes(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tbl,
                              long nr,
                              double const *time, double const *obsz, double const *obslon,
                              double const *obslat, double const *vpz, double const *vplon,
-                             double const *vplat, long *nseg, double *trace_part);
+                             double const *vplat, long *nseg, double *trace_part,
+                             double *ega_part);
 
 /* Function-level entry points for known-answer tests. */
 double orc_ega_eps(orc_tbl_t const *tbl, double tau, double t, double u, double p, int ig, int id);

@@ -41,7 +41,7 @@ def lib():
             [C.POINTER(C.c_int), dp, C.c_int]
         L.orc_algorithmic_bytes.restype = C.c_double
         L.orc_algorithmic_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long] + [dp] * 7 + \
-            [C.POINTER(C.c_long), dp]
+            [C.POINTER(C.c_long), dp, dp]
         for name, n in (("orc_ega_eps", 0), ("orc_ctmco2", 4), ("orc_ctmh2o", 5), ("orc_ctmn2", 3),
                         ("orc_ctmo2", 3), ("orc_planck", 2), ("orc_brightness", 2)):
             f = getattr(L, name)
@@ -113,9 +113,11 @@ def algorithmic_bytes(ctl, atm, tables, geom):
     g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
     nseg = C.c_long(0)
     tr = C.c_double(0)
+    eg = C.c_double(0)
     b = lib().orc_algorithmic_bytes(C.byref(ctl), C.byref(atm), tables.h, g.shape[1],
-                                    *[_p(g[k]) for k in range(7)], C.byref(nseg), C.byref(tr))
-    return dict(total=b, trace=tr.value, integrate=b - tr.value, segments=nseg.value, rays=g.shape[1])
+                                    *[_p(g[k]) for k in range(7)], C.byref(nseg), C.byref(tr), C.byref(eg))
+    return dict(total=b, trace=tr.value, ega=eg.value, combine=b - tr.value - eg.value,
+                integrate=b - tr.value, segments=nseg.value, rays=g.shape[1])
 
 
 def traceray(ctl, atm, geom7):

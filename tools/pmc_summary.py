@@ -6,7 +6,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        short = "integrate" if "jur_integrate" in k else "trace" if "jur_trace" in k else None
+        short = ("integrate" if "jur_integrate" in k else "trace" if "jur_trace" in k else
+                 "ega" if "jur_ega" in k else "combine" if "jur_combine" in k else None)
         if short is None:
             continue
         agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
