@@ -78,15 +78,14 @@ typedef struct {
   int *np;                      /* [n] LOS points per slot                      */
   double *tsurf;                /* [n]                                          */
   double *los;                  /* [nfield][JUR_NLOS][stride]                   */
-  double *eps;                  /* [nd*ng][JUR_NLOS][stride] segment transmittances (split path) or NULL */
+  double *eps;                  /* [nd*ng][JUR_NLOS][stride] segment transmittances */
   int *status;                  /* device flag: bit0 = NLOS overflow            */
 } jur_chunk_t;
 
 /* kernel launchers (jur_kernels.hip); return hipError_t as int */
 int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void *stream);
-int jurk_launch_integrate(jur_view_t const *v, jur_chunk_t const *c, void *stream);   /* fused form */
-int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *stream);         /* split form, 1/2 */
-int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, void *stream);     /* split form, 2/2 */
+int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *stream);
+int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 /* order rays by their geometric tangent altitude: fills order[nr]; `tmp` is a
  * device scratch of jurk_sort_tmp_bytes(nr) bytes */
 long jurk_sort_tmp_bytes(long nr);

@@ -5,13 +5,15 @@
 //                         per-segment state p, T, ds, k, q_H2O, u[g] to the LOS workspace
 //                         in [field][point][ray] order (coalesced over rays), the tangent
 //                         point, the point count and the surface temperature.
-//   jur_integrate_kernel  one lane per (ray, channel): sequential walk along the line of
-//                         sight with continua (jr_common.h:315-390), emissivity-growth
-//                         look-ups in the band tables (jr_common.h:237-280), Planck source
-//                         (:220-224) and the radiance update (:293-300); surface term,
-//                         brightness temperature and the NaN mask are fused in the epilogue
-//                         (CPUdrivers.c:5-24, jr_common.h:193-210).
-//                         Two table-search strategies: WARM (tables whose axes and curves
+//   jur_ega_kernel        one lane per ray, one (channel, gas) pair per workgroup: the sequential
+//                         emissivity-growth recurrence along the line of sight with its band
+//                         table look-ups (jr_common.h:237-280); writes the gas transmittance
+//                         of every segment.
+//   jur_combine_kernel    one lane per ray, one channel per workgroup: continua
+//                         (jr_common.h:315-390), product over gases, Planck source (:220-224),
+//                         radiance update (:293-300); surface term, brightness temperature and
+//                         the NaN mask in the epilogue (CPUdrivers.c:5-24, jr_common.h:193-210).
+//                         Two table-search strategies in jur_ega_kernel: WARM (tables whose axes and curves
 //                         are sorted: every bracket is unique, so the search resumes from
 //                         the bracket of the previous segment -- the accumulated
 //                         transmittance only falls, the column only grows) and EXACT (the
@@ -342,96 +344,79 @@ __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t
 struct __attribute__((aligned(16))) Lvl { double p; int nt; int c0; };
 struct __attribute__((aligned(16))) Crv { double t; int nu; int e0; };
 struct __attribute__((aligned(8))) Ue { float u; float eps; };
+struct __attribute__((aligned(8))) Ue2 { Ue a, b; };
 static_assert(sizeof(Lvl) == sizeof(jur_lvl_t) && sizeof(Crv) == sizeof(jur_crv_t) && sizeof(Ue) == sizeof(jur_ue_t), "layout");
+
+// Table element access as (wave-uniform base pointer) + (32-bit byte offset): the address is
+// formed by the memory instruction itself (SGPR base + VGPR offset) instead of 64-bit vector
+// arithmetic per load.  Offsets fit 32 bits: the host refuses tables beyond 2^28 entries.
+template <class T>
+__device__ __forceinline__ T ldg(void const *__restrict__ base, unsigned index) {
+  return *reinterpret_cast<T const *>(static_cast<char const *>(base) + (size_t)(index * (unsigned)sizeof(T)));
+}
+__device__ __forceinline__ Ue ld_ue(void const *__restrict__ ue, unsigned idx) { return ldg<Ue>(ue, idx); }
+// entries idx and idx+1 of a curve are adjacent: one 16-byte load
+__device__ __forceinline__ void ld_pair(void const *__restrict__ ue, unsigned idx, Ue &a, Ue &b) {
+  Ue2 const ab = *reinterpret_cast<Ue2 const *>(static_cast<char const *>(ue) + (size_t)(idx * 8u));
+  a = ab.a; b = ab.b;
+}
 
 template <bool ON_EPS>
 __device__ __forceinline__ double ukey(Ue const &e) { return ON_EPS ? (double)e.eps : (double)e.u; }
 
-// EXACT: the reference's bisection (locate_tbl_id, jr_common.h:116-125)
+// EXACT: the reference's bisection (locate_tbl_id, jr_common.h:116-125) on curve [e0, e0+n)
 template <bool ON_EPS>
-__device__ __forceinline__ int bisect_curve(Ue const *__restrict__ e, int n, double x) {
+__device__ __forceinline__ int bisect_curve(void const *__restrict__ ue, unsigned e0, int n, double x) {
   int ilo = 0, ihi = n - 1;
   while (ihi > ilo + 1) {
     int const i = (ihi + ilo) >> 1;
-    if (ukey<ON_EPS>(e[i]) > x) ihi = i; else ilo = i;
+    if (ukey<ON_EPS>(ld_ue(ue, e0 + i)) > x) ihi = i; else ilo = i;
   }
   return ilo;
-}
-
-struct __attribute__((aligned(8))) Ue2 { Ue a, b; };
-__device__ __forceinline__ void load_pair(Ue const *__restrict__ e, int i, Ue &a, Ue &b) {
-  Ue2 const ab = *reinterpret_cast<Ue2 const *>(e + i);   // entries i and i+1 are adjacent: one 16-byte load
-  a = ab.a; b = ab.b;
 }
 
 // WARM: move bracket i (entries a = e[i], b = e[i+1] already loaded) to the one that holds x:
 // key(e[i]) <= x < key(e[i+1]), clamped to [0, n-2].  One step is the common case; otherwise
 // gallop, then bisect inside the gap.
 template <bool ON_EPS>
-__device__ __forceinline__ void seek_curve(Ue const *__restrict__ e, int n, double x, int &i, Ue &a, Ue &b) {
+__device__ __forceinline__ void seek_curve(void const *__restrict__ ue, unsigned e0, int n, double x, int &i, Ue &a, Ue &b) {
   if (x >= ukey<ON_EPS>(b)) {
     if (i >= n - 2) return;
-    Ue const c = e[i + 2];
+    Ue const c = ld_ue(ue, e0 + i + 2);
     if (i + 2 >= n - 1 || ukey<ON_EPS>(c) > x) { ++i; a = b; b = c; return; }
     int lo = i + 2, hi, step = 2;
     for (;;) {
       hi = lo + step;
       if (hi >= n - 1) { hi = n - 1; break; }
-      if (ukey<ON_EPS>(e[hi]) > x) break;
+      if (ukey<ON_EPS>(ld_ue(ue, e0 + hi)) > x) break;
       lo = hi;
       step <<= 1;
     }
     while (hi > lo + 1) {
       int const mid = (lo + hi) >> 1;
-      if (ukey<ON_EPS>(e[mid]) > x) hi = mid; else lo = mid;
+      if (ukey<ON_EPS>(ld_ue(ue, e0 + mid)) > x) hi = mid; else lo = mid;
     }
     i = lo;
-    load_pair(e, i, a, b);
+    ld_pair(ue, e0 + i, a, b);
   } else if (x < ukey<ON_EPS>(a)) {
     if (i <= 0) return;
-    Ue const c = e[i - 1];
+    Ue const c = ld_ue(ue, e0 + i - 1);
     if (i - 1 <= 0 || ukey<ON_EPS>(c) <= x) { --i; b = a; a = c; return; }
     int hi = i - 1, lo, step = 2;
     for (;;) {
       lo = hi - step;
       if (lo <= 0) { lo = 0; break; }
-      if (ukey<ON_EPS>(e[lo]) <= x) break;
+      if (ukey<ON_EPS>(ld_ue(ue, e0 + lo)) <= x) break;
       hi = lo;
       step <<= 1;
     }
     while (hi > lo + 1) {
       int const mid = (lo + hi) >> 1;
-      if (ukey<ON_EPS>(e[mid]) > x) hi = mid; else lo = mid;
+      if (ukey<ON_EPS>(ld_ue(ue, e0 + mid)) > x) hi = mid; else lo = mid;
     }
     i = lo;
-    load_pair(e, i, a, b);
+    ld_pair(ue, e0 + i, a, b);
   }
-}
-
-// one (p,T) corner: u at which the curve reaches `eps`, then the curve's emissivity at that u
-// plus the segment's column (get_u, get_eps: jr_common.h:156-185)
-template <bool WARM>
-__device__ __forceinline__ double corner_eps(Ue const *__restrict__ e, int n, double eps, double u, int &idx) {
-  Ue a, b;
-  int i;
-  if (WARM) {
-    i = min(idx, n - 2);
-    load_pair(e, i, a, b);
-    seek_curve<true>(e, n, eps, i, a, b);
-    idx = i;
-  } else {
-    i = bisect_curve<true>(e, n, eps);
-    load_pair(e, i, a, b);
-  }
-  double const uc = lip((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps);
-  double const x = uc + u;
-  if (WARM) {
-    seek_curve<false>(e, n, x, i, a, b);
-  } else {
-    i = bisect_curve<false>(e, n, x);
-    load_pair(e, i, a, b);
-  }
-  return c01(lip((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, x));
 }
 
 // per-gas search state carried from segment to segment (WARM only):
@@ -442,72 +427,103 @@ __device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, dou
   if (tau < 1e-9) return 0.;
   jur_int2 const pr = v.pair[pair_idx];
   if (pr.a < 2) return 1.;
-  Lvl const *const lv = reinterpret_cast<Lvl const *>(v.lvl) + pr.b;
+  void const *const lvb = v.lvl;
+  void const *const cvb = v.crv;
+  void const *const ueb = v.ue;
+  unsigned const l_0 = (unsigned)pr.b;
   int ipr;
   Lvl l0, l1;
   if (WARM) {
     ipr = min((int)(br & 0xffu), pr.a - 2);
-    l0 = lv[ipr]; l1 = lv[ipr + 1];
-    while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = lv[ipr]; }
-    while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = lv[ipr + 1]; }
+    l0 = ldg<Lvl>(lvb, l_0 + ipr); l1 = ldg<Lvl>(lvb, l_0 + ipr + 1);
+    while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = ldg<Lvl>(lvb, l_0 + ipr); }
+    while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = ldg<Lvl>(lvb, l_0 + ipr + 1); }
   } else {  // locate_id, jr_common.h:106-114 (ascending-only bisection, whatever the axis looks like)
     int ilo = 0, ihi = pr.a - 1;
     while (ihi > ilo + 1) {
       int const i = (ihi + ilo) >> 1;
-      if (lv[i].p > p) ihi = i; else ilo = i;
+      if (ldg<Lvl>(lvb, l_0 + i).p > p) ihi = i; else ilo = i;
     }
     ipr = ilo;
-    l0 = lv[ipr]; l1 = lv[ipr + 1];
+    l0 = ldg<Lvl>(lvb, l_0 + ipr); l1 = ldg<Lvl>(lvb, l_0 + ipr + 1);
   }
   if (WARM) br = (br & ~0xffu) | (unsigned)ipr;
   if (l0.nt < 2 || l1.nt < 2) return 1.;
-  Crv const *const cv0 = reinterpret_cast<Crv const *>(v.crv) + l0.c0;
-  Crv const *const cv1 = reinterpret_cast<Crv const *>(v.crv) + l1.c0;
+  unsigned const k0 = (unsigned)l0.c0, k1 = (unsigned)l1.c0;
   int it0, it1;
   Crv c00, c01_, c10, c11;
   if (WARM) {
     it0 = min((int)((br >> 8) & 0xffu), l0.nt - 2);
-    c00 = cv0[it0]; c01_ = cv0[it0 + 1];
-    while (t < c00.t && it0 > 0) { --it0; c01_ = c00; c00 = cv0[it0]; }
-    while (t >= c01_.t && it0 < l0.nt - 2) { ++it0; c00 = c01_; c01_ = cv0[it0 + 1]; }
     it1 = min((int)((br >> 16) & 0xffu), l1.nt - 2);
-    c10 = cv1[it1]; c11 = cv1[it1 + 1];
-    while (t < c10.t && it1 > 0) { --it1; c11 = c10; c10 = cv1[it1]; }
-    while (t >= c11.t && it1 < l1.nt - 2) { ++it1; c10 = c11; c11 = cv1[it1 + 1]; }
+    c00 = ldg<Crv>(cvb, k0 + it0); c01_ = ldg<Crv>(cvb, k0 + it0 + 1);
+    c10 = ldg<Crv>(cvb, k1 + it1); c11 = ldg<Crv>(cvb, k1 + it1 + 1);
+    while (t < c00.t && it0 > 0) { --it0; c01_ = c00; c00 = ldg<Crv>(cvb, k0 + it0); }
+    while (t >= c01_.t && it0 < l0.nt - 2) { ++it0; c00 = c01_; c01_ = ldg<Crv>(cvb, k0 + it0 + 1); }
+    while (t < c10.t && it1 > 0) { --it1; c11 = c10; c10 = ldg<Crv>(cvb, k1 + it1); }
+    while (t >= c11.t && it1 < l1.nt - 2) { ++it1; c10 = c11; c11 = ldg<Crv>(cvb, k1 + it1 + 1); }
     br = (unsigned)ipr | ((unsigned)it0 << 8) | ((unsigned)it1 << 16);
     if (c00.nu < 2 || c01_.nu < 2 || c10.nu < 2 || c11.nu < 2) return 1.;
   } else {
     int ilo = 0, ihi = l0.nt - 1;
     while (ihi > ilo + 1) {
       int const i = (ihi + ilo) >> 1;
-      if (cv0[i].t > t) ihi = i; else ilo = i;
+      if (ldg<Crv>(cvb, k0 + i).t > t) ihi = i; else ilo = i;
     }
     it0 = ilo;
-    c00 = cv0[it0]; c01_ = cv0[it0 + 1];
+    c00 = ldg<Crv>(cvb, k0 + it0); c01_ = ldg<Crv>(cvb, k0 + it0 + 1);
     if (c00.nu < 2 || c01_.nu < 2) return 1.;
     ilo = 0; ihi = l1.nt - 1;
     while (ihi > ilo + 1) {
       int const i = (ihi + ilo) >> 1;
-      if (cv1[i].t > t) ihi = i; else ilo = i;
+      if (ldg<Crv>(cvb, k1 + i).t > t) ihi = i; else ilo = i;
     }
     it1 = ilo;
-    c10 = cv1[it1]; c11 = cv1[it1 + 1];
+    c10 = ldg<Crv>(cvb, k1 + it1); c11 = ldg<Crv>(cvb, k1 + it1 + 1);
     if (c10.nu < 2 || c11.nu < 2) return 1.;
   }
 
+  // the four (p,T) corners: u at which the curve reaches eps (get_u, jr_common.h:179-185), then the
+  // curve's emissivity at that u plus the segment's column (get_eps, :156-177).  The four curve
+  // loads of a stage are issued together.
   double const eps = 1 - tau;
-  Ue const *const ue = reinterpret_cast<Ue const *>(v.ue);
-  int i00 = (int)(ia & 0xffffu), i01 = (int)(ia >> 16), i10 = (int)(ib & 0xffffu), i11 = (int)(ib >> 16);
-  double const eps00 = corner_eps<WARM>(ue + c00.e0, c00.nu, eps, u, i00);
-  double const eps01 = corner_eps<WARM>(ue + c01_.e0, c01_.nu, eps, u, i01);
-  double const eps10 = corner_eps<WARM>(ue + c10.e0, c10.nu, eps, u, i10);
-  double const eps11 = corner_eps<WARM>(ue + c11.e0, c11.nu, eps, u, i11);
+  unsigned const e0[4] = {(unsigned)c00.e0, (unsigned)c01_.e0, (unsigned)c10.e0, (unsigned)c11.e0};
+  int const n[4] = {c00.nu, c01_.nu, c10.nu, c11.nu};
+  int i[4];
+  Ue a[4], b[4];
   if (WARM) {
-    ia = (unsigned)i00 | ((unsigned)i01 << 16);
-    ib = (unsigned)i10 | ((unsigned)i11 << 16);
+    i[0] = (int)(ia & 0xffffu); i[1] = (int)(ia >> 16); i[2] = (int)(ib & 0xffffu); i[3] = (int)(ib >> 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      i[k] = min(i[k], n[k] - 2);
+      ld_pair(ueb, e0[k] + i[k], a[k], b[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) seek_curve<true>(ueb, e0[k], n[k], eps, i[k], a[k], b[k]);
+    ia = (unsigned)i[0] | ((unsigned)i[1] << 16);
+    ib = (unsigned)i[2] | ((unsigned)i[3] << 16);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      i[k] = bisect_curve<true>(ueb, e0[k], n[k], eps);
+      ld_pair(ueb, e0[k] + i[k], a[k], b[k]);
+    }
   }
-  double const eps_p0 = c01(lip(c00.t, eps00, c01_.t, eps01, t));
-  double const eps_p1 = c01(lip(c10.t, eps10, c11.t, eps11, t));
+  double x[4], ec[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    x[k] = lip((double)a[k].eps, (double)a[k].u, (double)b[k].eps, (double)b[k].u, eps) + u;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (WARM) {
+      seek_curve<false>(ueb, e0[k], n[k], x[k], i[k], a[k], b[k]);   // the column only grows: start where get_u ended
+    } else {
+      i[k] = bisect_curve<false>(ueb, e0[k], n[k], x[k]);
+      ld_pair(ueb, e0[k] + i[k], a[k], b[k]);
+    }
+    ec[k] = c01(lip((double)a[k].u, (double)a[k].eps, (double)b[k].u, (double)b[k].eps, x[k]));
+  }
+  double const eps_p0 = c01(lip(c00.t, ec[0], c01_.t, ec[1], t));
+  double const eps_p1 = c01(lip(c10.t, ec[2], c11.t, ec[3], t));
   double const eps_t = c01(lip(l0.p, eps_p0, l1.p, eps_p1, p));
   return (1. - eps_t) / tau;
 }
@@ -551,101 +567,12 @@ __device__ __forceinline__ double planck_src(double const *__restrict__ sr, doub
 }
 
 // ---------------------------------------------------------------------------------------
-// along-path integration: one lane per ray, one channel per workgroup (blockIdx.y).  The 64
-// lanes of a wavefront are neighbouring rays of the sorted order looking into the SAME
-// (gas, channel) table, so their gathers fall into few cache lines; everything that depends
-// on the channel only is wave-uniform and lives in scalar registers.
-// ---------------------------------------------------------------------------------------
-#ifndef JUR_INT_WAVES
-#define JUR_INT_WAVES 3   /* measured: 3 waves/SIMD (168 VGPRs, 84 B scratch) beats 2 and 4 */
-#endif
-template <int NGT, bool WARM>
-__global__ __launch_bounds__(256, JUR_INT_WAVES) void jur_integrate_kernel(jur_view_t v, jur_chunk_t c) {
-  int const r = blockIdx.x * blockDim.x + threadIdx.x;   // slot in the chunk
-  int const nd = v.nd;
-  int const d = blockIdx.y;                              // channel, uniform
-  if (r >= c.n) return;
-  long const ray = c.order ? (long)c.order[r] : c.first + r;
-  size_t const R = (size_t)c.stride;
-  size_t const fs = (size_t)NLOS * R;
-  double const *const los = c.los + r;
-  jur_chan_t const ch = v.chan[d];
-  double const *const sr = v.sr + (size_t)d * TBLNS;
-  int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
-  int const ng = v.ng;
-  bool const do_co2 = (v.fourbit & 8) && ch.co2_on, do_h2o = (v.fourbit & 4) && ch.h2o_on,
-             do_n2 = (v.fourbit & 2) && ch.n2_on, do_o2 = (v.fourbit & 1) && ch.o2_on;
-
-  size_t const oidx = (size_t)ray * nd + d;
-  bool const masked = !isfinite(c.rad[oidx]);
-  double rad = 0.0, tau = 1.0;
-  double tau_path[NGT];
-  unsigned br[NGT], ia[NGT], ib[NGT];
-#pragma unroll
-  for (int g = 0; g < NGT; g++) { tau_path[g] = 1.0; br[g] = 0; ia[g] = 0; ib[g] = 0; }
-
-  int const np = c.np[r];
-  for (int ip = 0; ip < np; ++ip) {
-    // segment state: coalesced over the rays of the wavefront.  (Fetching the next point's state
-    // ahead of time was measured slower: the extra registers cost a wave per SIMD.)
-    size_t const o = (size_t)ip * R;
-    double const p = los[JUR_F_P * fs + o], t = los[JUR_F_T * fs + o], ds = los[JUR_F_DS * fs + o];
-    double const kx = los[f_k * fs + o];
-    double const qh = do_h2o ? los[JUR_F_QH2O * fs + o] : 0.;
-    double ug[NGT];
-#pragma unroll
-    for (int g = 0; g < NGT; g++) ug[g] = (g < ng) ? los[(f_u + g) * fs + o] : 0.;
-
-    // extinction and continua (jr_continua_core.mv4g.h:1-14)
-    double beta_ds = kx * ds;
-    if (do_co2) {
-      double uco2 = 0;
-#pragma unroll
-      for (int g = 0; g < NGT; g++) if (g == v.ig_co2) uco2 = ug[g];
-      beta_ds += ctm_co2(ch, p, t, uco2);
-    }
-    if (do_h2o) {
-      double uh2o = 0;
-#pragma unroll
-      for (int g = 0; g < NGT; g++) if (g == v.ig_h2o) uh2o = ug[g];
-      beta_ds += ctm_h2o(ch, p, t, qh, uh2o);
-    }
-    if (do_n2) beta_ds += ctm_n2(ch, p, t) * ds;
-    if (do_o2) beta_ds += ctm_o2(ch, p, t) * ds;
-
-    // gas transmittance of the segment by emissivity growth (jr_common.h:270-280)
-    double tau_gas = 1.0;
-#pragma unroll
-    for (int g = 0; g < NGT; g++) {
-      if (g < ng) {
-        double const eps = ega_eps<WARM>(v, g * nd + d, tau_path[g], t, ug[g], p, br[g], ia[g], ib[g]);
-        tau_path[g] *= eps;
-        tau_gas *= eps;
-      }
-    }
-
-    double const src = planck_src(sr, t);
-    if (tau_gas > 1e-50) {  // jr_common.h:293-300
-      double const eps = 1. - tau_gas * exp(-beta_ds);
-      rad += src * eps * tau;
-      tau *= (1. - eps);
-    }
-  }
-
-  double const tsurf = c.tsurf[r];
-  if (tsurf > 0.) rad += planck_src(sr, tsurf) * tau;  // jr_common.h:227-234
-  if (v.write_bbt) rad = JUR_C2 * ch.nu / log1p((JUR_C1 * ch.nu * ch.nu * ch.nu) / rad);  // :188-190
-  if (masked) rad = __builtin_nan("");
-  c.rad[oidx] = rad;
-  c.tau[oidx] = tau;
-}
-
-// ---------------------------------------------------------------------------------------
-// split form of the along-path integration (used when the workspace can hold the segment
-// transmittances): the emissivity-growth recurrence of every (ray, channel, gas) triple is an
-// independent sequential chain, so it gets its own lane -- ng x more lanes, a third of the
-// registers, 6+ waves per SIMD to hide the dependent table loads -- and hands its per-segment
-// transmittance to the combine kernel through HBM ([pair][point][ray], ray fastest).
+// along-path integration in two kernels.  The emissivity-growth recurrence of every (ray, channel,
+// gas) triple is an independent sequential chain, so it gets its own lane -- ng x more lanes than
+// one lane per (ray, channel), half the registers, 5 waves per SIMD to hide the dependent table
+// loads -- and hands its per-segment transmittance to the combine kernel through HBM
+// ([pair][point][ray], ray fastest).  (A fused single kernel with the gases unrolled in one lane
+// was measured 1.7x slower: 166+ VGPRs, 2-3 waves per SIMD.)
 //
 // jur_ega_kernel: one lane per ray, one (channel, gas) pair per workgroup.  Workgroups that
 // share a block of rays are made consecutive on one XCD (they re-read the same p, T, u lines
@@ -664,18 +591,19 @@ __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t 
   int const pair_idx = g * v.nd + d;
   if (v.pair[pair_idx].a < 2) return;            // no table: transmittance 1, the combine kernel knows
   size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
-  double const *const los = c.los + r;
-  double *const out = c.eps + (size_t)pr * fs + r;
-  int const f_u = JUR_F_K + v.nw + g;
+  // planes of the workspace are addressed as (uniform row pointer) + lane offset
+  double const *const los_p = c.los + JUR_F_P * fs, *const los_t = c.los + JUR_F_T * fs,
+               *const los_u = c.los + (size_t)(JUR_F_K + v.nw + g) * fs;
+  double *const out = c.eps + (size_t)pr * fs;
   int const np = c.np[r];
   double tau_path = 1.0;
   unsigned br = 0, ia = 0, ib = 0;
   for (int ip = 0; ip < np; ++ip) {
     size_t const o = (size_t)ip * R;
-    double const p = los[JUR_F_P * fs + o], t = los[JUR_F_T * fs + o], u = los[f_u * fs + o];
+    double const p = ldg<double>(los_p + o, r), t = ldg<double>(los_t + o, r), u = ldg<double>(los_u + o, r);
     double const eps = ega_eps<WARM>(v, pair_idx, tau_path, t, u, p, br, ia, ib);
     tau_path *= eps;
-    out[o] = eps;
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(out + o) + (size_t)((unsigned)r * 8u)) = eps;
   }
 }
 
@@ -688,8 +616,8 @@ __global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chun
   if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
   size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
-  double const *const los = c.los + r;
-  double const *const epsb = c.eps + (size_t)d * ng * fs + r;
+  double const *const los = c.los;
+  double const *const epsb = c.eps + (size_t)d * ng * fs;
   jur_chan_t const ch = v.chan[d];
   double const *const sr = v.sr + (size_t)d * TBLNS;
   int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
@@ -701,15 +629,16 @@ __global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chun
   int const np = c.np[r];
   for (int ip = 0; ip < np; ++ip) {
     size_t const o = (size_t)ip * R;
-    double const p = los[JUR_F_P * fs + o], t = los[JUR_F_T * fs + o], ds = los[JUR_F_DS * fs + o];
-    double beta_ds = los[f_k * fs + o] * ds;
-    if (do_co2) beta_ds += ctm_co2(ch, p, t, los[(f_u + v.ig_co2) * fs + o]);
-    if (do_h2o) beta_ds += ctm_h2o(ch, p, t, los[JUR_F_QH2O * fs + o], los[(f_u + v.ig_h2o) * fs + o]);
+    auto L = [&](int field) { return ldg<double>(los + (size_t)field * fs + o, r); };
+    double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
+    double beta_ds = L(f_k) * ds;
+    if (do_co2) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
+    if (do_h2o) beta_ds += ctm_h2o(ch, p, t, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
     if (do_n2) beta_ds += ctm_n2(ch, p, t) * ds;
     if (do_o2) beta_ds += ctm_o2(ch, p, t) * ds;
     double tau_gas = 1.0;
     for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
-      if (v.pair[g * nd + d].a >= 2) tau_gas *= epsb[(size_t)g * fs + o];
+      if (v.pair[g * nd + d].a >= 2) tau_gas *= ldg<double>(epsb + (size_t)g * fs + o, r);
     double const src = planck_src(sr, t);
     if (tau_gas > 1e-50) {  // jr_common.h:293-300
       double const eps = 1. - tau_gas * exp(-beta_ds);
@@ -769,30 +698,6 @@ extern "C" int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void
   int const block = 64;
   int const grid = (c->n + block - 1) / block;
   hipLaunchKernelGGL(jur_trace_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *v, *c);
-  return (int)hipGetLastError();
-}
-
-extern "C" int jurk_launch_integrate(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
-  if (c->n <= 0) return 0;
-  int const block = 256;
-  dim3 const grid((unsigned)((c->n + block - 1) / block), (unsigned)v->nd);
-  hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(N)                                                                                         \
-  do {                                                                                                    \
-    if (v->sorted_tables) hipLaunchKernelGGL((jur_integrate_kernel<N, true>), grid, dim3(block), 0, s, *v, *c); \
-    else hipLaunchKernelGGL((jur_integrate_kernel<N, false>), grid, dim3(block), 0, s, *v, *c);          \
-  } while (0)
-  if (v->ng <= 1) LAUNCH(1);
-  else if (v->ng <= 2) LAUNCH(2);
-  else if (v->ng <= 3) LAUNCH(3);
-  else if (v->ng <= 4) LAUNCH(4);
-  else if (v->ng <= 5) LAUNCH(5);
-  else if (v->ng <= 6) LAUNCH(6);
-  else if (v->ng <= 8) LAUNCH(8);
-  else if (v->ng <= 12) LAUNCH(12);
-  else if (v->ng <= 16) LAUNCH(16);
-  else LAUNCH(JUR_NG);
-#undef LAUNCH
   return (int)hipGetLastError();
 }
 

@@ -37,8 +37,7 @@ struct jur_model {
   int chunk_rays;               /* R                                             */
   int nfield;
   double *d_los;
-  double *d_eps;                /* split path: segment transmittances            */
-  int split;                    /* 1: ega + combine kernels, 0: fused integrate  */
+  double *d_eps;                /* segment transmittances per (channel, gas)     */
   long ws_budget;               /* bytes of workspace the model may hold         */
   long ws_rays;                 /* R the workspace is laid out for               */
   int *d_np;
@@ -154,7 +153,6 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   m->nfield = JUR_F_K + v->nw + v->ng;
   m->chunk_rays = 131072;
   m->sort_rays = 1;
-  m->split = (getenv("JUR_FUSED") && atoi(getenv("JUR_FUSED"))) ? 0 : 1;   /* A/B switch */
   m->ws_budget = 24L << 30;
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { jur_set_error("hipStreamCreate failed"); jur_model_destroy(m); return JUR_EHIP; }
   if ((rc = upload((void **)&m->d_status, NULL, sizeof(int)))) { jur_model_destroy(m); return rc; }
@@ -286,9 +284,9 @@ int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
 
 /* ---- workspace --------------------------------------------------------------- */
 static int ensure_workspace(jur_model_t *m, long nr) {
-  /* bytes per ray: LOS fields, plus one double per (channel, gas, point) on the split path */
+  /* bytes per ray: LOS fields, plus one double per (channel, gas, point) */
   long const per_ray_los = (long)sizeof(double) * m->nfield * JUR_NLOS;
-  long const per_ray_eps = m->split ? (long)sizeof(double) * m->view.nd * m->view.ng * JUR_NLOS : 0;
+  long const per_ray_eps = (long)sizeof(double) * m->view.nd * (m->view.ng > 0 ? m->view.ng : 1) * JUR_NLOS;
   long R = m->chunk_rays;
   long const fit = m->ws_budget / (per_ray_los + per_ray_eps);
   if (R > fit) R = fit / 64 * 64;
@@ -301,7 +299,7 @@ static int ensure_workspace(jur_model_t *m, long nr) {
     if (m->d_tsurf) (void)hipFree(m->d_tsurf);
     m->d_los = NULL; m->d_eps = NULL; m->d_np = NULL; m->d_tsurf = NULL; m->los_bytes = 0; m->ws_rays = 0;
     HIPCHK(hipMalloc((void **)&m->d_los, (size_t)per_ray_los * R));
-    if (per_ray_eps) HIPCHK(hipMalloc((void **)&m->d_eps, (size_t)per_ray_eps * R));
+    HIPCHK(hipMalloc((void **)&m->d_eps, (size_t)per_ray_eps * R));
     HIPCHK(hipMalloc((void **)&m->d_np, sizeof(int) * R));
     HIPCHK(hipMalloc((void **)&m->d_tsurf, sizeof(double) * R));
     m->los_bytes = (per_ray_los + per_ray_eps) * R;
@@ -341,7 +339,7 @@ int jur_model_enable_timing(jur_model_t *m, int on) {
 
 /* Sums the event-bracketed durations of the launches recorded since the last
  * call (at most JUR_MAX_TIMED chunks), then starts over.
- * [0] trace, [1] ega (split path) or fused integrate, [2] combine (split path). */
+ * [0] trace, [1] ega, [2] combine. */
 int jur_model_last_kernel_ms(jur_model_t *m, double out_ms[3], long out_launches[3]) {
   for (int k = 0; k < 3; k++) { out_ms[k] = 0; out_launches[k] = 0; }
   if (!m->evpool) return JUR_OK;
@@ -352,7 +350,6 @@ int jur_model_last_kernel_ms(jur_model_t *m, double out_ms[3], long out_launches
     for (int k = 0; k < 3; k++) {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-      if (k == 2 && !m->split) continue;
       out_ms[k] += ms; out_launches[k]++;
     }
   }
@@ -411,17 +408,11 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     int e = jurk_launch_trace(&m->view, &c, s);
     if (e) { jur_set_error("trace kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
     if (ev) HIPCHK(hipEventRecord(ev[1], s));
-    if (m->split) {
-      e = jurk_launch_ega(&m->view, &c, s);
-      if (e) { jur_set_error("ega kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
-      if (ev) HIPCHK(hipEventRecord(ev[2], s));
-      e = jurk_launch_combine(&m->view, &c, s);
-      if (e) { jur_set_error("combine kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
-    } else {
-      e = jurk_launch_integrate(&m->view, &c, s);
-      if (e) { jur_set_error("integrate kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
-      if (ev) HIPCHK(hipEventRecord(ev[2], s));
-    }
+    e = jurk_launch_ega(&m->view, &c, s);
+    if (e) { jur_set_error("ega kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
+    if (ev) HIPCHK(hipEventRecord(ev[2], s));
+    e = jurk_launch_combine(&m->view, &c, s);
+    if (e) { jur_set_error("combine kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
     if (ev) {
       HIPCHK(hipEventRecord(ev[3], s));
       m->ntimed++;

@@ -315,7 +315,10 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
       for (int it = 0; it < tb->pair[i].lv[ip].nt; it++) nentry += tb->pair[i].lv[ip].cv[it].nu;
     }
   }
-  if (nentry >= 0x7fffffffL) { jur_set_error("tables too large for 32-bit offsets (%ld entries)", nentry); return JUR_EINVAL; }
+  if (nentry >= (1L << 28) || ncurve >= (1L << 27) || nlevel >= (1L << 27)) {  /* kernels address with 32-bit byte offsets */
+    jur_set_error("tables too large for 32-bit byte offsets (%ld entries)", nentry);
+    return JUR_EINVAL;
+  }
   out->nlevel = nlevel; out->ncurve = ncurve; out->nentry = nentry;
   out->pair = (jur_int2 *)calloc(npair > 0 ? npair : 1, sizeof(jur_int2));
   out->lvl = (jur_lvl_t *)calloc(nlevel + 2, sizeof(jur_lvl_t));
