@@ -53,7 +53,7 @@ typedef struct {
   jur_ue_t const *ue;
   int sorted_tables;            /* every axis and curve is non-decreasing: any bracket search
                                    finds what the reference's bisection finds                  */
-  int pad2;
+  int atm_maxslice;             /* longest run of equal time stamps in the atmosphere          */
   /* atmosphere, compact SoA of atm_np points */
   int atm_np;
   int atm_sorted;               /* time stamps non-decreasing and z strictly monotone inside every slice */

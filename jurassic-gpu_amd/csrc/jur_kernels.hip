@@ -187,14 +187,17 @@ __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t
       }
     }
 
-    // bookkeeping for the tangent point: the three points around the lowest one
+    // Bookkeeping for the tangent point: the three points around the lowest one.  Longitude and
+    // latitude of a LOS point are only ever needed for the point before the exit (clipping), the two
+    // neighbours of the lowest point and the last point, so the per-step asin/atan2 of cart2geo is
+    // deferred: the Cartesian position is kept and converted on demand (same input, same result).
     double z_low = 1e99;
     int low_idx = -1;
-    double pz = 0, plon = 0, plat = 0;                      // previous point (np-1)
-    double lz0 = 0, llon0 = 0, llat0 = 0;                   // point low_idx-1
+    double pz = 0, px[3] = {0, 0, 0};                       // previous point (np-1)
+    double lz0 = 0, lx0[3] = {0, 0, 0};                     // point low_idx-1
     double lz1 = 0, lds1 = 0;                               // point low_idx
-    double lz2 = 0, llon2 = 0, llat2 = 0, lds2 = 0;         // point low_idx+1
-    double last_z = 0, last_lon = 0, last_lat = 0;
+    double lz2 = 0, lx2[3] = {0, 0, 0}, lds2 = 0;           // point low_idx+1
+    double last_z = 0;
 
     // altitude brackets are resumed from the previous point when the slice's axis is strictly monotone
     int const zdir = (v.atm_sorted && atmn >= 2) ? ((v.atm_z[atm0] < v.atm_z[atm0 + 1]) ? 1 : -1) : 0;
@@ -211,17 +214,18 @@ __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t
         double const cosa = fabs(dot);
         if (cosa != 0.) ds = fmin(ds, dz / cosa);
       }
-      double z, lon, lat;
-      cart2geo(x, z, lon, lat);
+      double z = norm3(x) - JUR_RE;
       if ((z < zmin) || (z > zmax)) {  // LOS left the atmosphere: clip the last segment (:637-648)
         double xh[3];
         stop = (z < zmin) ? 2 : 1;
         if (np > 0) {
+          double pzz, plon, plat;
+          cart2geo(px, pzz, plon, plat);   // == the previous point's stored geolocation upstream
           geo2cart(pz, plon, plat, xh);
           double const zfrac = (z < zmin) ? zmin : zmax;
           double const frac = (zfrac - pz) / (z - pz);
           for (int i = 0; i < 3; i++) x[i] = xh[i] + frac * (x[i] - xh[i]);
-          cart2geo(x, z, lon, lat);
+          z = norm3(x) - JUR_RE;
           double const dsp = ds * frac;
           F(JUR_F_DS, np - 1) = dsp;
           if (low_idx == np - 1) lds1 = dsp;
@@ -249,15 +253,17 @@ __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t
       F(JUR_F_T, np) = t;
       F(JUR_F_DS, np) = ds;
 
-      if (low_idx >= 0 && low_idx == np - 1) { lz2 = z; llon2 = lon; llat2 = lat; lds2 = ds; }
+      if (low_idx >= 0 && low_idx == np - 1) { lz2 = z; lds2 = ds; for (int i = 0; i < 3; i++) lx2[i] = x[i]; }
       if (z < z_low) {
         z_low = z;
         low_idx = np;
-        lz0 = pz; llon0 = plon; llat0 = plat;
+        lz0 = pz;
+        for (int i = 0; i < 3; i++) lx0[i] = px[i];
         lz1 = z; lds1 = ds;
       }
-      last_z = z; last_lon = lon; last_lat = lat;
-      pz = z; plon = lon; plat = lat;
+      last_z = z;
+      pz = z;
+      for (int i = 0; i < 3; i++) px[i] = x[i];
 
       if (stop) {
         tsurf = (stop == 2 ? t : -999);
@@ -298,7 +304,9 @@ __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t
 
     // tangent point from the raw segment lengths (jr_common.h:502-539)
     if (low_idx <= 0 || low_idx >= np - 1) {
-      tpz = last_z; tplon = last_lon; tplat = last_lat;
+      double zz;
+      cart2geo(px, zz, tplon, tplat);   // px is the last point here
+      tpz = last_z;
     } else {
       double const yy0 = lz0, yy1 = lz1, yy2 = lz2, ds0 = lds1, ds1 = lds2,
                    dyy10 = yy1 - yy0, dyy21 = yy2 - yy1,
@@ -310,7 +318,9 @@ __global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t
                    cc = yy0,
                    xt = -b / (2 * a);
       tpz = (a * xt + b) * xt + cc;
-      double w[3], v0[3], v2[3], dummy;
+      double w[3], v0[3], v2[3], dummy, llon0, llat0, llon2, llat2;
+      cart2geo(lx0, dummy, llon0, llat0);
+      cart2geo(lx2, dummy, llon2, llat2);
       geo2cart(lz0, llon0, llat0, v0);
       geo2cart(lz2, llon2, llat2, v2);
       for (int i = 0; i < 3; i++) w[i] = lip(0.0, v0[i], x2, v2[i], xt);

@@ -263,7 +263,10 @@ int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
   if (e != hipSuccess) { jur_set_error("atm upload failed: %s", hipGetErrorString(e)); return JUR_EHIP; }
   m->atm_slices = 1;
   v->atm_sorted = 1;
-  for (int i = 1, dir = 0; i < n; i++) {
+  v->atm_maxslice = 1;
+  for (int i = 1, dir = 0, run = 1; i < n; i++) {
+    run = (atm->time[i] != atm->time[i - 1]) ? 1 : run + 1;
+    if (run > v->atm_maxslice) v->atm_maxslice = run;
     if (atm->time[i] != atm->time[i - 1]) {
       m->atm_slices++;
       if (atm->time[i] < atm->time[i - 1]) v->atm_sorted = 0;

@@ -26,18 +26,24 @@ def table_rows(emitter, nu, id_=0, nlev=33, ntemp=10, descending=False, umax_eps
     plev = np.exp(np.linspace(np.log(0.016), np.log(1000.0), nlev))
     if descending:
         plev = plev[::-1]
-    rows = []
+    nmax = 2 + int(np.ceil(np.log(1e12) / np.log(ratio))) if ratio > 1 else 400
+    steps = np.full(nmax, ratio)
+    blocks = []
     for il, p in enumerate(plev):
         for t in 180.0 + 2.0 * (il % 3) + 15.0 * np.arange(ntemp):
             k = k0 * np.sqrt(p / 1000.0) * 250.0 / t
-            u = (1e-6 ** (1 / 0.7)) / k
-            while True:
-                eps = 1.0 - np.exp(-(k * u) ** 0.7)
-                rows.append((p, t, u, eps))
-                if eps > umax_eps:
-                    break
-                u *= ratio
-    return np.array(rows)
+            steps[0] = (1e-6 ** (1 / 0.7)) / k
+            u = np.cumprod(steps)                      # u0, u0*r, (u0*r)*r, ... left to right
+            eps = 1.0 - np.exp(-(k * u) ** 0.7)
+            hit = np.nonzero(eps > umax_eps)[0]
+            n = (hit[0] + 1) if len(hit) else nmax     # the row that crosses the limit is the last one
+            blk = np.empty((n, 4))
+            blk[:, 0] = p
+            blk[:, 1] = t
+            blk[:, 2] = u[:n]
+            blk[:, 3] = eps[:n]
+            blocks.append(blk)
+    return np.vstack(blocks)
 
 
 def write_table_file(path, rows):

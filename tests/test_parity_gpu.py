@@ -171,6 +171,51 @@ def test_drop_in_formod_reads_reference_files(hip, oracle, tmp_path):
     assert np.ctypeslib.as_array(one.rad)[16, 0] == 7.0          # other rays untouched
 
 
+def test_hundred_channels_three_gases(hip, oracle):
+    """Many-channel shape (BASELINE configs[4] scaled to the compiled ND = 100): 100 channels
+    650..2665 cm^-1 spanning all four continuum windows, CO2/H2O/O3 tables per channel (300
+    tables, 20 M entries -- larger than L2), nadir and limb rays."""
+    nu = list(np.round(np.linspace(650.0, 2665.0, 100), 4))
+    geom = np.vstack([synth.nadir_geometry(300, seed=3), synth.limb_geometry(300, seed=4)])
+    case = common.Case(["CO2", "H2O", "O3"], nu, os.path.join(common.GOLD, "limb", "atm.tab"), geom)
+    out, ref = run_both(hip, oracle, case)
+    assert_parity(out, ref)
+
+
+DROPIN_NADIR = r"""
+import os, sys
+sys.path[:0] = [{root!r}, os.path.join({root!r}, 'jurassic-gpu_amd'), os.path.join({root!r}, 'tests')]
+import numpy as np, common
+from oracle import orc
+from jurassic_hip import abi, lib, textio
+case = common.nadir_case(useGPU=-1)
+for d, nu in enumerate(common.NADIR_NU):
+    case.filters[d] = tuple(np.loadtxt(os.path.join(common.GOLD, 'nadir', 'airs_%.4f.filt' % nu), comments='#').T)
+case.write_files({tmp!r}, base='airs')
+obs = textio.read_obs(os.path.join(common.GOLD, 'nadir', 'obs.tab'), case.ctl, max_rays=90)
+ref = textio.read_obs(os.path.join(common.GOLD, 'nadir', 'obs.tab'), case.ctl, max_rays=90)
+tb = orc.Tables(1, 3); assert tb.read_ascii(case.ctl) == 0 and tb.planck_filt(case.ctl) == 0
+orc.formod(case.ctl, case.atm, ref, tb)
+lib.formod(case.ctl, case.atm, obs)
+a, b = np.ctypeslib.as_array(obs.rad)[:90, :3], np.ctypeslib.as_array(ref.rad)[:90, :3]
+assert np.all((a > 150) & (a < 320)), a[:2]
+assert np.max(np.abs(a - b) / b) < 1e-9
+gold = textio.read_obs_array(os.path.join(common.GOLD, 'nadir', 'rad.org'), 3)
+assert all('%g' % x == '%g' % y for x, y in zip(np.ctypeslib.as_array(obs.tplat)[:90], gold[:, 9]))
+print('DROPIN_NADIR_OK')
+"""
+
+
+def test_drop_in_nadir_in_fresh_process(hip, oracle, tmp_path):
+    """The drop-in entry caches its tables for the life of the process (as upstream), so the
+    second configuration -- example/nadir: AIRS filters, WRITE_BBT=1, USEGPU=-1 -- runs in a
+    process of its own."""
+    script = tmp_path / "dropin_nadir.py"
+    script.write_text(DROPIN_NADIR.format(root=common.ROOT, tmp=str(tmp_path)))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DROPIN_NADIR_OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_large_batch_properties(hip, oracle):
     """BASELINE configs[2] at full size (1e6 limb rays, 4 channels, 5 emitters, 64
     profiles): properties that need no oracle run at that size, plus a sampled
