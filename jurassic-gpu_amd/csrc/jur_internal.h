@@ -60,6 +60,7 @@ typedef struct {
   double const *atm_time, *atm_z, *atm_lon, *atm_lat, *atm_p, *atm_t;
   double const *atm_q;          /* [ng][atm_np] */
   double const *atm_k;          /* [nw][atm_np] */
+  double const *atm_pslope;     /* [atm_np] ln-pressure slope to the next level, NaN if not defined */
 } jur_view_t;
 
 /* One chunk of rays handed to the kernels; all pointers are device memory.
@@ -83,6 +84,7 @@ typedef struct {
 } jur_chunk_t;
 
 /* kernel launchers (jur_kernels.hip); return hipError_t as int */
+int jurk_prepare_atm(jur_view_t const *v, double *d_pslope, void *stream);   /* fills atm_pslope */
 int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, void *stream);

@@ -113,9 +113,25 @@ __device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, dou
   hint = loc;
   int const ip = i0 + loc;
   double const za = v.atm_z[ip], zb = v.atm_z[ip + 1];
-  p = eip(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0);
+  // eip (jr_common.h:53-57) with log(p1/p0)/(z1-z0) taken from the per-level array that
+  // jur_pslope_kernel filled with exactly that expression; NaN marks a non-positive pressure
+  double const sl = v.atm_pslope[ip];
+  p = (sl == sl) ? v.atm_p[ip] * exp(sl * (z0 - za)) : lip(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0);
   t = lip(za, v.atm_t[ip], zb, v.atm_t[ip + 1], z0);
   return ip;
+}
+
+// once per atmosphere upload: slope of ln p between neighbouring levels, as eip forms it
+__global__ void jur_pslope_kernel(int n, double const *__restrict__ z, double const *__restrict__ p,
+                                  double *__restrict__ slope) {
+  int const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = __builtin_nan("");
+  if (i + 1 < n) {
+    double const y0 = p[i], y1 = p[i + 1];
+    if ((y0 > 0) && (y1 > 0)) s = log(y1 / y0) / (z[i + 1] - z[i]);
+  }
+  slope[i] = s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -619,10 +635,14 @@ __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t 
 
 // jur_combine_kernel: one lane per ray, one channel per workgroup: continua, product of the gas
 // transmittances in the reference's order, Planck source, radiance update, epilogue.
-__global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chunk_t c) {
-  int const r = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
   int const nd = v.nd, ng = v.ng;
-  int const d = blockIdx.y;
+  // same XCD-aware order as jur_ega_kernel: the nd workgroups of one ray block follow each other
+  // on one XCD and share the block's LOS rows in that L2
+  int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
+  int const rb = (sq / nd) * 8 + xcd, d = sq - (sq / nd) * nd;   // ray block, channel: uniform
+  if (rb >= nrb) return;
+  int const r = rb * blockDim.x + threadIdx.x;
   if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
   size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
@@ -703,6 +723,13 @@ __global__ __launch_bounds__(256) void jur_raykey_kernel(long nr, double const *
 
 }  // namespace
 
+extern "C" int jurk_prepare_atm(jur_view_t const *v, double *d_pslope, void *stream) {
+  int const block = 256;
+  hipLaunchKernelGGL(jur_pslope_kernel, dim3((v->atm_np + block - 1) / block), dim3(block), 0, (hipStream_t)stream,
+                     v->atm_np, v->atm_z, v->atm_p, d_pslope);
+  return (int)hipGetLastError();
+}
+
 extern "C" int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
   if (c->n <= 0) return 0;
   int const block = 64;
@@ -725,8 +752,9 @@ extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *
 extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
   if (c->n <= 0) return 0;
   int const block = 256;
-  dim3 const grid((unsigned)((c->n + block - 1) / block), (unsigned)v->nd);
-  hipLaunchKernelGGL(jur_combine_kernel, grid, dim3(block), 0, (hipStream_t)stream, *v, *c);
+  int const nrb = (c->n + block - 1) / block;
+  unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * v->nd);
+  hipLaunchKernelGGL(jur_combine_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *v, *c, nrb);
   return (int)hipGetLastError();
 }
 

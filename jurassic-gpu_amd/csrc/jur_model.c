@@ -252,7 +252,7 @@ int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
   if (n > m->atm_cap) {
     if (m->d_atm) (void)hipFree(m->d_atm);
     m->d_atm = NULL;
-    hipError_t e = hipMalloc(&m->d_atm, sizeof(double) * nrow * n);
+    hipError_t e = hipMalloc(&m->d_atm, sizeof(double) * (nrow + 1) * n);   /* + one row for atm_pslope */
     if (e != hipSuccess) { free(h); jur_set_error("hipMalloc(atm) failed"); return JUR_EHIP; }
     m->atm_cap = n;
   }
@@ -282,6 +282,11 @@ int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
   v->atm_time = d; v->atm_z = d + (size_t)n; v->atm_lon = d + 2 * (size_t)n; v->atm_lat = d + 3 * (size_t)n;
   v->atm_p = d + 4 * (size_t)n; v->atm_t = d + 5 * (size_t)n;
   v->atm_q = d + 6 * (size_t)n; v->atm_k = d + (6 + (size_t)ng) * n;
+  v->atm_pslope = d + nrow * (size_t)n;
+  {
+    int const ek = jurk_prepare_atm(v, (double *)m->d_atm + nrow * (size_t)n, m->stream);
+    if (ek || hipStreamSynchronize(m->stream) != hipSuccess) { jur_set_error("atm preparation kernel failed"); return JUR_EHIP; }
+  }
   return JUR_OK;
 }
 
