@@ -94,6 +94,17 @@ int  jur_formod_device(jur_model_t *m, long nr, double const *d_geom,
                        double *d_rad, double *d_tau, double *d_tp, int *d_np,
                        int *d_status, void *stream);
 
+/* Retrieval support (reference kernel(), jurassic.c:812-857; state/measurement
+ * vectors as atm2x/obs2y, :1491-1541): forward-difference Jacobian dy/dx of the
+ * finite radiances with respect to the atmosphere values inside the
+ * ctl->ret{p,t,q,k}_zmin/zmax windows, evaluated as one batched forward-model
+ * call (n+1 stacked atmospheres).  k is row-major [jur_measurement_size][jur_state_size];
+ * obs returns the unperturbed result.  The reference's signature takes a gsl_matrix;
+ * bind with k = matrix->data when matrix->tda == matrix->size2. */
+size_t jur_state_size(jur_model_t const *m, atm_t const *atm);
+size_t jur_measurement_size(jur_model_t const *m, obs_t const *obs);
+int    jur_kernel(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t mrows, size_t ncols);
+
 /* Bytes of device workspace the model holds for `nr` rays per call, and the
  * chunk size (rays per kernel launch) it uses. */
 long jur_model_workspace_bytes(jur_model_t const *m);

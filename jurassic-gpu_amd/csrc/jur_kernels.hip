@@ -586,7 +586,9 @@ __device__ __forceinline__ double ctm_o2(jur_chan_t const &ch, double p, double 
 }
 
 __device__ __forceinline__ double planck_src(double const *__restrict__ sr, double t) {
-  int const it = (int)(4 * t) - 400;  // 0.25 K grid from 100 K (jr_common.h:82-84; no range check upstream)
+  // 0.25 K grid from 100 K (locate_st, jr_common.h:82-84).  Upstream has no range check and reads
+  // outside the table for T outside [100, 400) K; here the index is clamped (end intervals extrapolate).
+  int const it = min(max((int)(4 * t) - 400, 0), TBLNS - 2);
   double const st0 = 100 + ((double)it - 0.0) * (400 - 100) / ((TBLNS - 1.0) - 0.0);
   double const st1 = 100 + ((double)(it + 1) - 0.0) * (400 - 100) / ((TBLNS - 1.0) - 0.0);
   return lip(st0, sr[it], st1, sr[it + 1], t);

@@ -230,64 +230,82 @@ static void hydrostatic(ctl_t const *ctl, int ig_h2o, int n, double const *z, do
   for (int ip = ipref - 1; ip >= 0; ip--) layer_pressure(z, t, q, p, lat[ipref], ip + 1, ip);
 }
 
-int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
-  if (!m || !atm || atm->np < 2 || atm->np > JUR_NP) { jur_set_error("set_atm: need 2..%d atmospheric points", JUR_NP); return JUR_EINVAL; }
+/* Host image of an atmosphere: rows time, z, lon, lat, p, T, q[ng], k[nw], each n long. */
+static void pack_atm_rows(jur_model_t const *m, atm_t const *atm, double *h, size_t stride, size_t at) {
+  int const n = atm->np, ng = m->view.ng, nw = m->view.nw;
+  memcpy(h + 0 * stride + at, atm->time, sizeof(double) * n);
+  memcpy(h + 1 * stride + at, atm->z, sizeof(double) * n);
+  memcpy(h + 2 * stride + at, atm->lon, sizeof(double) * n);
+  memcpy(h + 3 * stride + at, atm->lat, sizeof(double) * n);
+  memcpy(h + 4 * stride + at, atm->p, sizeof(double) * n);
+  memcpy(h + 5 * stride + at, atm->t, sizeof(double) * n);
+  for (int g = 0; g < ng; g++) memcpy(h + (6 + (size_t)g) * stride + at, atm->q[g], sizeof(double) * n);
+  for (int w = 0; w < nw; w++) memcpy(h + (6 + (size_t)ng + w) * stride + at, atm->k[w], sizeof(double) * n);
+}
+
+/* hydrostatic adjustment of one packed atmosphere of n points starting at `at` (CPUdrivers.c:98-103) */
+static void hydrostatic_rows(jur_model_t const *m, double *h, size_t stride, size_t at, int n) {
+  if (m->ctl->hydz < 0) return;
+  int const ig = m->view.ig_h2o;
+  hydrostatic(m->ctl, ig, n, h + 1 * stride + at, h + 3 * stride + at, h + 5 * stride + at,
+              ig >= 0 ? h + (6 + (size_t)ig) * stride + at : NULL, h + 4 * stride + at);
+}
+
+/* upload packed rows [6+ng+nw][n] and derive what the kernels want to know about them */
+static int upload_atm_rows(jur_model_t *m, double const *h, long n) {
   HIPCHK(hipSetDevice(m->device));
   jur_view_t *v = &m->view;
-  int const n = atm->np, ng = v->ng, nw = v->nw;
+  int const ng = v->ng, nw = v->nw;
   size_t const nrow = 6 + (size_t)ng + nw;
-  double *h = (double *)malloc(sizeof(double) * nrow * n);
-  if (!h) return JUR_ENOMEM;
-  memcpy(h + 0 * (size_t)n, atm->time, sizeof(double) * n);
-  memcpy(h + 1 * (size_t)n, atm->z, sizeof(double) * n);
-  memcpy(h + 2 * (size_t)n, atm->lon, sizeof(double) * n);
-  memcpy(h + 3 * (size_t)n, atm->lat, sizeof(double) * n);
-  memcpy(h + 4 * (size_t)n, atm->p, sizeof(double) * n);
-  memcpy(h + 5 * (size_t)n, atm->t, sizeof(double) * n);
-  for (int g = 0; g < ng; g++) memcpy(h + (6 + (size_t)g) * n, atm->q[g], sizeof(double) * n);
-  for (int w = 0; w < nw; w++) memcpy(h + (6 + (size_t)ng + w) * n, atm->k[w], sizeof(double) * n);
-  if (!(m->ctl->hydz < 0))  /* CPUdrivers.c:98-103; applied to the private copy */
-    hydrostatic(m->ctl, v->ig_h2o, n, h + 1 * (size_t)n, h + 3 * (size_t)n, h + 5 * (size_t)n,
-                v->ig_h2o >= 0 ? h + (6 + (size_t)v->ig_h2o) * n : NULL, h + 4 * (size_t)n);
   if (n > m->atm_cap) {
     if (m->d_atm) (void)hipFree(m->d_atm);
     m->d_atm = NULL;
-    hipError_t e = hipMalloc(&m->d_atm, sizeof(double) * (nrow + 1) * n);   /* + one row for atm_pslope */
-    if (e != hipSuccess) { free(h); jur_set_error("hipMalloc(atm) failed"); return JUR_EHIP; }
+    m->atm_cap = 0;
+    HIPCHK(hipMalloc(&m->d_atm, sizeof(double) * (nrow + 1) * (size_t)n));   /* + one row for atm_pslope */
     m->atm_cap = n;
   }
   /* ordered behind earlier work on the model's stream */
-  hipError_t e = hipMemcpyAsync(m->d_atm, h, sizeof(double) * nrow * n, hipMemcpyHostToDevice, m->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
-  free(h);
-  if (e != hipSuccess) { jur_set_error("atm upload failed: %s", hipGetErrorString(e)); return JUR_EHIP; }
+  HIPCHK(hipMemcpyAsync(m->d_atm, h, sizeof(double) * nrow * (size_t)n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  double const *time = h, *z = h + (size_t)n;
   m->atm_slices = 1;
   v->atm_sorted = 1;
   v->atm_maxslice = 1;
-  for (int i = 1, dir = 0, run = 1; i < n; i++) {
-    run = (atm->time[i] != atm->time[i - 1]) ? 1 : run + 1;
-    if (run > v->atm_maxslice) v->atm_maxslice = run;
-    if (atm->time[i] != atm->time[i - 1]) {
+  for (long i = 1, dir = 0, run = 1; i < n; i++) {
+    run = (time[i] != time[i - 1]) ? 1 : run + 1;
+    if (run > v->atm_maxslice) v->atm_maxslice = (int)run;
+    if (time[i] != time[i - 1]) {
       m->atm_slices++;
-      if (atm->time[i] < atm->time[i - 1]) v->atm_sorted = 0;
+      if (time[i] < time[i - 1]) v->atm_sorted = 0;
       dir = 0;
       continue;
     }
-    int const d = (atm->z[i] > atm->z[i - 1]) - (atm->z[i] < atm->z[i - 1]);
+    long const d = (z[i] > z[i - 1]) - (z[i] < z[i - 1]);
     if (d == 0 || (dir != 0 && d != dir)) v->atm_sorted = 0;
     dir = d;
   }
   double const *d = (double const *)m->d_atm;
-  v->atm_np = n;
+  v->atm_np = (int)n;
   v->atm_time = d; v->atm_z = d + (size_t)n; v->atm_lon = d + 2 * (size_t)n; v->atm_lat = d + 3 * (size_t)n;
   v->atm_p = d + 4 * (size_t)n; v->atm_t = d + 5 * (size_t)n;
   v->atm_q = d + 6 * (size_t)n; v->atm_k = d + (6 + (size_t)ng) * n;
   v->atm_pslope = d + nrow * (size_t)n;
-  {
-    int const ek = jurk_prepare_atm(v, (double *)m->d_atm + nrow * (size_t)n, m->stream);
-    if (ek || hipStreamSynchronize(m->stream) != hipSuccess) { jur_set_error("atm preparation kernel failed"); return JUR_EHIP; }
-  }
+  int const ek = jurk_prepare_atm(v, (double *)m->d_atm + nrow * (size_t)n, m->stream);
+  if (ek || hipStreamSynchronize(m->stream) != hipSuccess) { jur_set_error("atm preparation kernel failed"); return JUR_EHIP; }
   return JUR_OK;
+}
+
+int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
+  if (!m || !atm || atm->np < 2 || atm->np > JUR_NP) { jur_set_error("set_atm: need 2..%d atmospheric points", JUR_NP); return JUR_EINVAL; }
+  int const n = atm->np;
+  size_t const nrow = 6 + (size_t)m->view.ng + m->view.nw;
+  double *h = (double *)malloc(sizeof(double) * nrow * n);
+  if (!h) return JUR_ENOMEM;
+  pack_atm_rows(m, atm, h, (size_t)n, 0);
+  hydrostatic_rows(m, h, (size_t)n, 0, n);   /* on the private copy; the caller's atm is not modified */
+  int const rc = upload_atm_rows(m, h, n);
+  free(h);
+  return rc;
 }
 
 /* ---- workspace --------------------------------------------------------------- */
@@ -370,6 +388,7 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
                       int *d_np, int *d_status, void *stream) {
   if (!m || nr < 0) { jur_set_error("formod_device: bad arguments"); return JUR_EINVAL; }
   if (nr == 0) return JUR_OK;
+  if (nr > 0x7fffffffL) { jur_set_error("formod_device: at most 2^31-1 rays per call"); return JUR_EINVAL; }
   if (m->view.atm_np < 2) { jur_set_error("formod_device: no atmosphere set"); return JUR_EINVAL; }
   HIPCHK(hipSetDevice(m->device));
   int rc = ensure_workspace(m, nr);
@@ -462,6 +481,124 @@ int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double
   HIPCHK(hipStreamSynchronize(s));
   if (status & 1) { jur_set_error("Too many LOS points! (a ray needs %d or more)", JUR_NLOS); return JUR_ENLOS; }
   return JUR_OK;
+}
+
+/* ---- retrieval Jacobian -------------------------------------------------------- */
+/* State vector of the atmosphere inside the retrieval windows (atm2x, jurassic.c:1491-1513):
+ * quantity index iqa (0 p, 1 T, 2+g q, 2+ng+w k) and atmosphere point ipa per element. */
+static size_t state_vector(ctl_t const *ctl, atm_t const *atm, double *x, int *iqa, int *ipa) {
+  size_t n = 0;
+  int const nquant = 2 + ctl->ng + ctl->nw;
+  for (int iq = 0; iq < nquant; iq++) {
+    double zmin, zmax;
+    double const *value;
+    if (iq == 0) { zmin = ctl->retp_zmin; zmax = ctl->retp_zmax; value = atm->p; }
+    else if (iq == 1) { zmin = ctl->rett_zmin; zmax = ctl->rett_zmax; value = atm->t; }
+    else if (iq < 2 + ctl->ng) { zmin = ctl->retq_zmin[iq - 2]; zmax = ctl->retq_zmax[iq - 2]; value = atm->q[iq - 2]; }
+    else { int const w = iq - 2 - ctl->ng; zmin = ctl->retk_zmin[w]; zmax = ctl->retk_zmax[w]; value = atm->k[w]; }
+    for (int ip = 0; ip < atm->np; ip++)
+      if (atm->z[ip] >= zmin && atm->z[ip] <= zmax) {
+        if (x) x[n] = value[ip];
+        if (iqa) iqa[n] = iq;
+        if (ipa) ipa[n] = ip;
+        n++;
+      }
+  }
+  return n;
+}
+
+size_t jur_state_size(jur_model_t const *m, atm_t const *atm) { return state_vector(m->ctl, atm, NULL, NULL, NULL); }
+
+size_t jur_measurement_size(jur_model_t const *m, obs_t const *obs) {
+  size_t n = 0;
+  for (int ir = 0; ir < obs->nr; ir++)
+    for (int id = 0; id < m->view.nd; id++) n += isfinite(obs->rad[ir][id]) ? 1 : 0;
+  return n;
+}
+
+/* Forward-difference Jacobian (kernel(), jurassic.c:812-857) as ONE batched forward-model call:
+ * the n perturbed atmospheres are stacked behind the unperturbed one as further profile slices
+ * (time stamps shifted by j * span) and every ray is replicated once per slice. */
+int jur_kernel(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t mrows, size_t ncols) {
+  if (!m || !atm || !obs || !k) { jur_set_error("jur_kernel: null argument"); return JUR_EINVAL; }
+  ctl_t const *ctl = m->ctl;
+  int const np0 = atm->np, nr = obs->nr, nd = ctl->nd, ng = m->view.ng, nw = m->view.nw;
+  if (np0 < 2 || np0 > JUR_NP || nr < 1 || nr > JUR_NR) { jur_set_error("jur_kernel: bad atm->np / obs->nr"); return JUR_EINVAL; }
+  size_t const n = state_vector(ctl, atm, NULL, NULL, NULL);
+  if (n != ncols) { jur_set_error("jur_kernel: state vector has %zu elements, matrix has %zu columns", n, ncols); return JUR_EINVAL; }
+  if (jur_measurement_size(m, obs) != mrows) { jur_set_error("jur_kernel: measurement vector size does not match the matrix rows"); return JUR_EINVAL; }
+  double *x0 = (double *)malloc(sizeof(double) * (n + 1)), *hstep = (double *)malloc(sizeof(double) * (n + 1));
+  int *iqa = (int *)malloc(sizeof(int) * (n + 1)), *ipa = (int *)malloc(sizeof(int) * (n + 1));
+  state_vector(ctl, atm, x0, iqa, ipa);
+
+  size_t const ncopy = n + 1, nrow = 6 + (size_t)ng + nw;
+  size_t const NT = ncopy * (size_t)np0, NRT = ncopy * (size_t)nr;
+  double *h = (double *)malloc(sizeof(double) * nrow * NT);
+  double *g = (double *)malloc(sizeof(double) * (10 + 2 * (size_t)nd) * NRT);
+  int rc = JUR_OK;
+  if (!x0 || !hstep || !iqa || !ipa || !h || !g) { rc = JUR_ENOMEM; goto done; }
+  {
+    double tmin = atm->time[0], tmax = atm->time[0];
+    for (int i = 0; i < np0; i++) { tmin = fmin(tmin, atm->time[i]); tmax = fmax(tmax, atm->time[i]); }
+    for (int i = 0; i < nr; i++) { tmin = fmin(tmin, obs->time[i]); tmax = fmax(tmax, obs->time[i]); }
+    double const span = (tmax - tmin) + 1.0;
+    for (size_t j = 0; j < ncopy; j++) {
+      size_t const at = j * (size_t)np0;
+      pack_atm_rows(m, atm, h, NT, at);
+      if (j > 0) {  /* perturbation sizes, jurassic.c:831-837 */
+        size_t const e = j - 1;
+        int const iq = iqa[e];
+        double hh;
+        if (iq == 0) hh = fmax(fabs(0.01 * x0[e]), 1e-7);
+        else if (iq == 1) hh = 1;
+        else if (iq < 2 + ng) hh = fmax(fabs(0.01 * x0[e]), 1e-15);
+        else hh = 1e-4;
+        hstep[e] = hh;
+        size_t const row = (iq == 0) ? 4 : (iq == 1) ? 5 : (size_t)(4 + iq);   /* q rows start at 6, k rows follow */
+        h[row * NT + at + ipa[e]] = x0[e] + hh;
+      }
+      hydrostatic_rows(m, h, NT, at, np0);
+      for (int i = 0; i < np0; i++) h[at + i] = atm->time[i] + (double)j * span;
+    }
+    rc = upload_atm_rows(m, h, (long)NT);
+    if (rc) goto done;
+    double *geom[7], *tp[3], *rad, *tau;
+    for (int q = 0; q < 7; q++) geom[q] = g + (size_t)q * NRT;
+    for (int q = 0; q < 3; q++) tp[q] = g + (size_t)(7 + q) * NRT;
+    rad = g + 10 * NRT;
+    tau = rad + (size_t)nd * NRT;
+    double const *src[7] = {obs->time, obs->obsz, obs->obslon, obs->obslat, obs->vpz, obs->vplon, obs->vplat};
+    for (size_t j = 0; j < ncopy; j++)
+      for (int i = 0; i < nr; i++) {
+        size_t const r = j * (size_t)nr + i;
+        geom[0][r] = src[0][i] + (double)j * span;
+        for (int q = 1; q < 7; q++) geom[q][r] = src[q][i];
+        for (int id = 0; id < nd; id++) rad[r * nd + id] = obs->rad[i][id];   /* carries the NaN mask */
+      }
+    double const *cgeom[7] = {geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6]};
+    rc = jur_formod_host(m, (long)NRT, cgeom, rad, tau, tp, NULL);
+    if (rc) goto done;
+    for (int i = 0; i < nr; i++) {   /* unperturbed result back to the caller, as kernel() leaves it */
+      for (int id = 0; id < nd; id++) { obs->rad[i][id] = rad[(size_t)i * nd + id]; obs->tau[i][id] = tau[(size_t)i * nd + id]; }
+      for (int id = nd; id < JUR_ND; id++) { obs->rad[i][id] = 0.0; obs->tau[i][id] = 1.0; }
+      obs->tpz[i] = tp[0][i]; obs->tplon[i] = tp[1][i]; obs->tplat[i] = tp[2][i];
+    }
+    size_t row = 0;
+    for (int i = 0; i < nr; i++)
+      for (int id = 0; id < nd; id++) {
+        double const y0 = rad[(size_t)i * nd + id];
+        if (!isfinite(y0)) continue;               /* obs2y, jurassic.c:1527-1541 */
+        for (size_t e = 0; e < n; e++) {
+          double const y1 = rad[((e + 1) * (size_t)nr + i) * nd + id];
+          k[row * n + e] = (y1 - y0) / hstep[e];
+        }
+        row++;
+      }
+  }
+done:
+  free(x0); free(hstep); free(iqa); free(ipa); free(h); free(g);
+  if (rc == JUR_OK) rc = jur_model_set_atm(m, atm);   /* leave the model with the caller's atmosphere */
+  return rc;
 }
 
 /* ---- drop-in entry points ------------------------------------------------------ */

@@ -62,6 +62,11 @@ def make_ctl(emitters, nu, tblbase="-", **kw):
     ctl.rayds = 10.0
     ctl.raydz = 0.5
     ctl.fov = b"-"
+    ctl.retp_zmin = ctl.retp_zmax = ctl.rett_zmin = ctl.rett_zmax = -999.0
+    for g in range(NG):
+        ctl.retq_zmin[g] = ctl.retq_zmax[g] = -999.0
+    for w in range(NW):
+        ctl.retk_zmin[w] = ctl.retk_zmax[w] = -999.0
     ctl.formod = 2
     ctl.read_binary = -1
     ctl.write_binary = 1

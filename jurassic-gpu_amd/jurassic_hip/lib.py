@@ -49,6 +49,11 @@ def lib():
         L.jur_model_set_workspace_budget.argtypes = [C.c_void_p, C.c_long]
         L.jur_model_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_last_kernel_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
+        L.jur_state_size.restype = C.c_size_t
+        L.jur_state_size.argtypes = [C.c_void_p, C.c_void_p]
+        L.jur_measurement_size.restype = C.c_size_t
+        L.jur_measurement_size.argtypes = [C.c_void_p, C.c_void_p]
+        L.jur_kernel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, dp, C.c_size_t, C.c_size_t]
         L.jur_abi_sizes.argtypes = [C.POINTER(C.c_size_t)]
         for name in ("formod", "formod_GPU"):
             getattr(L, name).argtypes = [C.c_void_p] * 3
@@ -149,6 +154,14 @@ class Model:
     def formod_device(self, nr, d_geom, d_rad, d_tau, d_tp, d_np=0, d_status=0, stream=0):
         """All arguments are raw device addresses (ints), e.g. torch_tensor.data_ptr()."""
         _chk(lib().jur_formod_device(self.h, nr, d_geom, d_rad, d_tau, d_tp, d_np, d_status, stream))
+
+    def kernel(self, atm, obs):
+        """Forward-difference Jacobian (m, n); obs receives the unperturbed forward model."""
+        n = lib().jur_state_size(self.h, C.byref(atm))
+        m = lib().jur_measurement_size(self.h, C.byref(obs))
+        k = np.zeros((m, n))
+        _chk(lib().jur_kernel(self.h, C.byref(atm), C.byref(obs), _p(k), m, n))
+        return k
 
     def enable_timing(self, on=True):
         _chk(lib().jur_model_enable_timing(self.h, int(on)))

@@ -845,3 +845,91 @@ double orc_algorithmic_bytes(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tb, 
   if (ega_part) *ega_part = tega;
   return total;
 }
+
+/* ------------------------------------------------------------------------ */
+/* retrieval interface: state/measurement vectors and the finite-difference   */
+/* Jacobian, jurassic.c:812-857 (kernel), :1473-1541 (x2atm, atm2x, obs2y)    */
+/* ------------------------------------------------------------------------ */
+#define IDXP 0
+#define IDXT 1
+#define IDXQ(ig) (2 + (ig))
+#define IDXK(iw) (2 + ctl->ng + (iw))
+
+static void atm2x_help(atm_t const *atm, double zmin, double zmax, double const *value, int val_iqa, double *x,
+                       int *iqa, int *ipa, size_t *n) {
+  for (int ip = 0; ip < atm->np; ip++)
+    if (atm->z[ip] >= zmin && atm->z[ip] <= zmax) {
+      if (x) x[*n] = value[ip];
+      if (iqa) iqa[*n] = val_iqa;
+      if (ipa) ipa[*n] = ip;
+      (*n)++;
+    }
+}
+
+size_t orc_atm2x(ctl_t const *ctl, atm_t const *atm, double *x, int *iqa, int *ipa) {
+  size_t n = 0;
+  atm2x_help(atm, ctl->retp_zmin, ctl->retp_zmax, atm->p, IDXP, x, iqa, ipa, &n);
+  atm2x_help(atm, ctl->rett_zmin, ctl->rett_zmax, atm->t, IDXT, x, iqa, ipa, &n);
+  for (int ig = 0; ig < ctl->ng; ig++)
+    atm2x_help(atm, ctl->retq_zmin[ig], ctl->retq_zmax[ig], atm->q[ig], IDXQ(ig), x, iqa, ipa, &n);
+  for (int iw = 0; iw < ctl->nw; iw++)
+    atm2x_help(atm, ctl->retk_zmin[iw], ctl->retk_zmax[iw], atm->k[iw], IDXK(iw), x, iqa, ipa, &n);
+  return n;
+}
+
+static void x2atm_help(atm_t *atm, double zmin, double zmax, double *value, double const *x, size_t *n) {
+  for (int ip = 0; ip < atm->np; ip++)
+    if ((atm->z[ip] >= zmin) && (atm->z[ip] <= zmax)) {
+      value[ip] = x[*n];
+      (*n)++;
+    }
+}
+
+static void x2atm(ctl_t const *ctl, double const *x, atm_t *atm) {
+  size_t n = 0;
+  x2atm_help(atm, ctl->retp_zmin, ctl->retp_zmax, atm->p, x, &n);
+  x2atm_help(atm, ctl->rett_zmin, ctl->rett_zmax, atm->t, x, &n);
+  for (int ig = 0; ig < ctl->ng; ig++) x2atm_help(atm, ctl->retq_zmin[ig], ctl->retq_zmax[ig], atm->q[ig], x, &n);
+  for (int iw = 0; iw < ctl->nw; iw++) x2atm_help(atm, ctl->retk_zmin[iw], ctl->retk_zmax[iw], atm->k[iw], x, &n);
+}
+
+size_t orc_obs2y(ctl_t const *ctl, obs_t const *obs, double *y) {
+  size_t m = 0;
+  for (int ir = 0; ir < obs->nr; ir++)
+    for (int id = 0; id < ctl->nd; id++)
+      if (isfinite(obs->rad[ir][id])) {
+        if (y) y[m] = obs->rad[ir][id];
+        ++m;
+      }
+  return m;
+}
+
+/* k is row-major m x n; obs holds the unperturbed result on return. */
+void orc_kernel(ctl_t const *ctl, atm_t *atm, obs_t *obs, orc_tbl_t const *tb, double *k, size_t m, size_t n) {
+  int *iqa = (int *)malloc(sizeof(int) * (n + 1));
+  double *x0 = (double *)malloc(sizeof(double) * (n + 1)), *x1 = (double *)malloc(sizeof(double) * (n + 1));
+  double *yy0 = (double *)malloc(sizeof(double) * (m + 1)), *yy1 = (double *)malloc(sizeof(double) * (m + 1));
+  atm_t *atm1 = (atm_t *)malloc(sizeof(atm_t));
+  obs_t *obs1 = (obs_t *)malloc(sizeof(obs_t));
+  orc_formod(ctl, atm, obs, tb);
+  orc_atm2x(ctl, atm, x0, iqa, NULL);
+  orc_obs2y(ctl, obs, yy0);
+  memset(k, 0, sizeof(double) * m * n);
+  for (size_t j = 0; j < n; j++) {
+    double h;
+    if (iqa[j] == IDXP) h = fmax(fabs(0.01 * x0[j]), 1e-7);
+    else if (iqa[j] == IDXT) h = 1;
+    else if (iqa[j] >= IDXQ(0) && iqa[j] < IDXQ(ctl->ng)) h = fmax(fabs(0.01 * x0[j]), 1e-15);
+    else if (iqa[j] >= IDXK(0) && iqa[j] < IDXK(ctl->nw)) h = 1e-4;
+    else { fprintf(stderr, "oracle: cannot set perturbation size\n"); exit(1); }
+    memcpy(x1, x0, sizeof(double) * n);
+    x1[j] = x1[j] + h;
+    memcpy(atm1, atm, sizeof(atm_t));               /* copy_atm(..., 0) */
+    memcpy(obs1, obs, sizeof(obs_t));               /* copy_obs(..., 0) */
+    x2atm(ctl, x1, atm1);
+    orc_formod(ctl, atm1, obs1, tb);
+    orc_obs2y(ctl, obs1, yy1);
+    for (size_t i = 0; i < m; i++) k[i * n + j] = (yy1[i] - yy0[i]) / h;
+  }
+  free(iqa); free(x0); free(x1); free(yy0); free(yy1); free(atm1); free(obs1);
+}

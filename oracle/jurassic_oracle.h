@@ -90,6 +90,15 @@ double orc_algorithmic_bytes(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tbl,
                              double const *vplat, long *nseg, double *trace_part,
                              double *ega_part);
 
+/* Retrieval interface (jurassic.c:812-857, 1473-1541): state vector of the
+ * atmosphere inside the ctl->ret*_zmin/zmax windows, measurement vector of the
+ * finite radiances, and the forward-difference Jacobian k[m][n] (row-major).
+ * orc_kernel leaves the unperturbed forward model result in obs. */
+size_t orc_atm2x(ctl_t const *ctl, atm_t const *atm, double *x, int *iqa, int *ipa);
+size_t orc_obs2y(ctl_t const *ctl, obs_t const *obs, double *y);
+void   orc_kernel(ctl_t const *ctl, atm_t *atm, obs_t *obs, orc_tbl_t const *tbl,
+                  double *k, size_t m, size_t n);
+
 /* Function-level entry points for known-answer tests. */
 double orc_ega_eps(orc_tbl_t const *tbl, double tau, double t, double u, double p, int ig, int id);
 double orc_ctmco2(double nu, double p, double t, double u);

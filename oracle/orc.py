@@ -52,6 +52,11 @@ def lib():
         L.orc_traceray.restype = C.c_int
         L.orc_traceray.argtypes = [C.c_void_p, C.c_void_p] + [dp] * 12
         L.orc_hydrostatic.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_atm2x.restype = C.c_size_t
+        L.orc_atm2x.argtypes = [C.c_void_p, C.c_void_p, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_obs2y.restype = C.c_size_t
+        L.orc_obs2y.argtypes = [C.c_void_p, C.c_void_p, dp]
+        L.orc_kernel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dp, C.c_size_t, C.c_size_t]
         _lib = L
     return _lib
 
@@ -134,3 +139,16 @@ def traceray(ctl, atm, geom7):
     res = {k: v[:npts] for k, v in out.items()}
     res.update(q=q[:ctl.ng, :npts], u=u[:ctl.ng, :npts], np=npts, tsurf=tsurf[0], tp=tp)
     return res
+
+
+def state_size(ctl, atm):
+    return lib().orc_atm2x(C.byref(ctl), C.byref(atm), None, None, None)
+
+
+def kernel(ctl, atm, obs, tables):
+    """Forward-difference Jacobian (m, n) of the reference's kernel(); obs gets the base result."""
+    n = state_size(ctl, atm)
+    m = sum(1 for ir in range(obs.nr) for d in range(ctl.nd) if np.isfinite(obs.rad[ir][d]))
+    k = np.zeros((m, n))
+    lib().orc_kernel(C.byref(ctl), C.byref(atm), C.byref(obs), tables.h, _p(k), m, n)
+    return k

@@ -142,3 +142,32 @@ def test_algorithmic_bytes_per_ray_matches_survey_estimate(oracle):
     assert ab["segments"] == 16708
     assert 1.5e6 < ab["total"] / ab["rays"] < 1.9e6
     assert 0 < ab["trace"] < 0.1 * ab["total"]
+
+
+def test_oracle_jacobian_is_consistent_with_two_forward_runs(oracle):
+    """kernel() column j is (F(x + h e_j) - F(x)) / h (jurassic.c:830-849): rebuild two columns by hand."""
+    case = common.limb_case(geom=common.golden_geometry("limb")[::6])
+    c = case.ctl
+    c.rett_zmin, c.rett_zmax = 10.0, 12.0                 # 3 temperature elements
+    c.retq_zmin[1], c.retq_zmax[1] = 5.0, 5.0             # 1 H2O element
+    tb = case.oracle_tables(oracle)
+    obs = abi.obs_t()
+    obs.nr = len(case.geom)
+    for k, name in enumerate(("time", "obsz", "obslon", "obslat", "vpz", "vplon", "vplat")):
+        np.ctypeslib.as_array(getattr(obs, name))[:obs.nr] = case.geom[:, k]
+    K = oracle.kernel(c, case.atm, obs, tb)
+    assert K.shape == (obs.nr * 2, 4)
+    base = oracle.formod_rays(c, case.atm, tb, case.geom)["rad"].ravel()
+    t = np.ctypeslib.as_array(case.atm.t)
+    t[11] += 1.0                                          # element 1 of the state vector: T at 11 km, h = 1
+    col = (oracle.formod_rays(c, case.atm, tb, case.geom)["rad"].ravel() - base) / 1.0
+    t[11] -= 1.0
+    assert np.allclose(K[:, 1], col, rtol=1e-12, atol=0)
+    q = np.ctypeslib.as_array(case.atm.q)
+    h = max(abs(0.01 * q[1, 5]), 1e-15)
+    q0 = q[1, 5]
+    q[1, 5] = q0 + h
+    col = (oracle.formod_rays(c, case.atm, tb, case.geom)["rad"].ravel() - base) / h
+    q[1, 5] = q0
+    assert np.allclose(K[:, 3], col, rtol=1e-12, atol=0)
+    assert np.all(K[:, :3].max(axis=0) > 0)               # warmer air radiates more

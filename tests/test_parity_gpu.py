@@ -216,6 +216,47 @@ def test_drop_in_nadir_in_fresh_process(hip, oracle, tmp_path):
     assert out.returncode == 0 and "DROPIN_NADIR_OK" in out.stdout, out.stdout + out.stderr
 
 
+def _retrieval_case(**kw):
+    case = common.limb_case(**kw)
+    c = case.ctl
+    c.retp_zmin, c.retp_zmax = 20.0, 25.0
+    c.rett_zmin, c.rett_zmax = 10.0, 40.0
+    for g in range(c.ng):
+        c.retq_zmin[g], c.retq_zmax[g] = -999.0, -999.0
+    c.retq_zmin[2], c.retq_zmax[2] = 15.0, 35.0          # O3
+    c.retk_zmin[0], c.retk_zmax[0] = 10.0, 20.0
+    return case
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(hydz=10.0)])
+def test_jacobian_matches_reference_kernel(hip, oracle, kw):
+    """jur_kernel (one batched call over n+1 stacked atmospheres) against the restated
+    kernel() loop of n+1 formod calls (jurassic.c:812-857).  Columns are difference quotients
+    (y1-y0)/h: compared relative to the largest entry of each column."""
+    case = _retrieval_case(**kw)
+    obs_ref = _obs_from_geom(case.geom, 2)
+    obs = _obs_from_geom(case.geom, 2)
+    for o in (obs_ref, obs):
+        o.rad[5][1] = float("nan")                        # a masked measurement drops its row
+    k_ref = oracle.kernel(case.ctl, case.atm, obs_ref, case.oracle_tables(oracle))
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    k = model.kernel(case.atm, obs)
+    assert k.shape == k_ref.shape == (66 * 2 - 1, 6 + 31 + 21 + 11)
+    scale = np.abs(k_ref).max(axis=0)
+    live = scale > 0          # with HYDZ >= 0 the pressure columns away from the reference level vanish
+    assert live.sum() >= 31 + 21 + 11 and np.all(k[:, ~live] == 0)
+    assert np.max(np.abs(k[:, live] - k_ref[:, live]) / scale[live]) < 1e-6
+    n = obs.nr
+    a, b = np.ctypeslib.as_array(obs.rad)[:n, :2], np.ctypeslib.as_array(obs_ref.rad)[:n, :2]
+    fin = np.isfinite(b)
+    assert np.array_equal(fin, np.isfinite(a)) and common.rel_err(a[fin], b[fin]).max() < RTOL
+    # the model is left with the caller's atmosphere
+    again = model.formod_host(case.geom)
+    assert common.rel_err(again["rad"][fin], b[fin]).max() < RTOL
+    model.close()
+
+
 def test_large_batch_properties(hip, oracle):
     """BASELINE configs[2] at full size (1e6 limb rays, 4 channels, 5 emitters, 64
     profiles): properties that need no oracle run at that size, plus a sampled
