@@ -61,6 +61,16 @@ int jur_tables_read_ascii(jur_tables_t *tb, ctl_t const *ctl);
 /* Filter function of one channel -> source-function table (jurassic.c:612-667). */
 int jur_tables_set_filter(jur_tables_t *tb, int id, int n, double const *nu, double const *f);
 int jur_tables_read_filters(jur_tables_t *tb, ctl_t const *ctl);
+/* Compact binary cache of parsed tables + source functions (own format: text header naming
+ * emitters and channels, then the flattened arrays and a checksum; ~8 bytes per table entry).
+ * jur_tables_load: JUR_OK, JUR_EIO (no file) or JUR_EINVAL (other emitters/channels, damaged).
+ * jur_model_create_from_files uses it under `bin.jurassic-hip-tables-g<ng>-d<nd>` in the
+ * working directory as ctl->read_binary / ctl->write_binary ask (reference jurassic.c:312-320). */
+int  jur_tables_save(jur_tables_t const *tb, ctl_t const *ctl, char const *path);
+int  jur_tables_load(jur_tables_t **out, ctl_t const *ctl, char const *path);
+void jur_tables_cache_filename(char *out, size_t len, ctl_t const *ctl);
+/* FNV-1a over the flattened tables and source functions */
+unsigned long long jur_tables_checksum(jur_tables_t const *tb);
 /* number of stored (u,eps) entries, for reporting */
 long jur_tables_entries(jur_tables_t const *tb);
 

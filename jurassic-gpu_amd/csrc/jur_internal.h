@@ -132,6 +132,7 @@ typedef struct {
 int  jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out);
 void jur_flat_free(jur_flat_t *f);
 
+void jur_tables_cache_filename(char *out, size_t len, ctl_t const *ctl);
 void jur_chan_setup(jur_chan_t *ch, double nu, int window);
 void jur_set_error(char const *fmt, ...);
 

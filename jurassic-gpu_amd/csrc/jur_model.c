@@ -165,13 +165,27 @@ int jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device)
   *out = NULL;
   int rc = check_ctl(ctl);
   if (rc) return rc;
-  jur_tables_t *tb = jur_tables_new(ctl->ng, ctl->nd);
-  if (!tb) return JUR_ENOMEM;
-  rc = jur_tables_read_ascii(tb, ctl);
-  if (rc >= 0) {
-    int const found = rc;
-    if (found < ctl->ng * ctl->nd) printf("Warning! %d files were not found!\n", ctl->ng * ctl->nd - found);
-    rc = jur_tables_read_filters(tb, ctl);
+  /* READ_BINARY / WRITE_BINARY as upstream's init_tbl (jurassic.c:312-320, 669-671): != 0 try the
+   * cache first, > 0 insist on it; write it after parsing the ASCII files when WRITE_BINARY != 0. */
+  char cache[256];
+  jur_tables_cache_filename(cache, sizeof cache, ctl);
+  jur_tables_t *tb = NULL;
+  if (ctl->read_binary) {
+    rc = jur_tables_load(&tb, ctl, cache);
+    if (rc == JUR_OK) printf("matching binary tables file found\n");
+    else if (ctl->read_binary > 0) return rc;
+  }
+  if (!tb) {
+    tb = jur_tables_new(ctl->ng, ctl->nd);
+    if (!tb) return JUR_ENOMEM;
+    rc = jur_tables_read_ascii(tb, ctl);
+    if (rc >= 0) {
+      int const found = rc;
+      if (found < ctl->ng * ctl->nd) printf("Warning! %d files were not found!\n", ctl->ng * ctl->nd - found);
+      rc = jur_tables_read_filters(tb, ctl);
+    }
+    if (rc == JUR_OK && ctl->write_binary && jur_tables_save(tb, ctl, cache) != JUR_OK)
+      printf("Warning! could not write %s: %s\n", cache, jur_last_error());
   }
   if (rc == JUR_OK) rc = jur_model_create(out, ctl, tb, device);
   jur_tables_free(tb);

@@ -358,3 +358,155 @@ void jur_flat_free(jur_flat_t *f) {
   free(f->pair); free(f->lvl); free(f->crv); free(f->ue);
   memset(f, 0, sizeof *f);
 }
+
+/* ---- compact binary cache (own format; upstream's cache is a raw dump of its dense 8.8 GB
+ *      tbl_t, jr_binary_tables_io.h:213-233) ------------------------------------------------ */
+#define JUR_CACHE_MAGIC "JURASSIC-HIP compact emissivity tables\n"
+#define JUR_CACHE_VERSION 1
+
+void jur_tables_cache_filename(char *out, size_t len, ctl_t const *ctl) {
+  snprintf(out, len, "bin.jurassic-hip-tables-g%d-d%d", ctl->ng, ctl->nd);   /* cf. jr_binary_tables_io.h:12-16 */
+}
+
+unsigned long long jur_tables_checksum(jur_tables_t const *tb) {
+  jur_flat_t fl;
+  if (jur_tables_flatten(tb, &fl)) return 0;
+  unsigned long long h = 1469598103934665603ULL;                      /* FNV-1a over the flattened image */
+  struct { void const *p; size_t n; } part[] = {
+    {fl.pair, sizeof(jur_int2) * (size_t)tb->ng * tb->nd}, {fl.lvl, sizeof(jur_lvl_t) * fl.nlevel},
+    {fl.crv, sizeof(jur_crv_t) * fl.ncurve}, {fl.ue, sizeof(jur_ue_t) * fl.nentry},
+    {tb->sr, sizeof(double) * JUR_TBLNS * (size_t)tb->nd}};
+  for (size_t k = 0; k < sizeof part / sizeof part[0]; k++) {
+    unsigned char const *b = (unsigned char const *)part[k].p;
+    for (size_t i = 0; i < part[k].n; i++) { h ^= b[i]; h *= 1099511628211ULL; }
+  }
+  jur_flat_free(&fl);
+  return h;
+}
+
+static int cache_header(char *buf, size_t len, ctl_t const *ctl, jur_flat_t const *fl) {
+  int n = snprintf(buf, len, JUR_CACHE_MAGIC "version %d\nng %d\nnd %d\nnlevel %ld\nncurve %ld\nnentry %ld\ntblns %d\n",
+                   JUR_CACHE_VERSION, ctl->ng, ctl->nd, fl ? fl->nlevel : 0L, fl ? fl->ncurve : 0L, fl ? fl->nentry : 0L,
+                   JUR_TBLNS);
+  for (int ig = 0; ig < ctl->ng && n < (int)len; ig++) n += snprintf(buf + n, len - n, "emitter %d %s\n", ig, ctl->emitter[ig]);
+  for (int id = 0; id < ctl->nd && n < (int)len; id++) n += snprintf(buf + n, len - n, "channel %d %.4f\n", id, ctl->nu[id]);
+  if (n < (int)len) n += snprintf(buf + n, len - n, "header_end\n");
+  return (n < (int)len) ? n : -1;
+}
+
+int jur_tables_save(jur_tables_t const *tb, ctl_t const *ctl, char const *path) {
+  if (!tb || tb->ng != ctl->ng || tb->nd != ctl->nd) { jur_set_error("tables_save: tables do not match ctl"); return JUR_EINVAL; }
+  jur_flat_t fl;
+  int rc = jur_tables_flatten(tb, &fl);
+  if (rc) return rc;
+  size_t const hlen = 256 + 64 * ((size_t)ctl->ng + ctl->nd) + (size_t)ctl->ng * JUR_LEN;
+  char *hdr = (char *)malloc(hlen);
+  int const n = hdr ? cache_header(hdr, hlen, ctl, &fl) : -1;
+  FILE *out = (n > 0) ? fopen(path, "wb") : NULL;
+  if (!out) { free(hdr); jur_flat_free(&fl); jur_set_error("cannot write table cache %s", path); return JUR_EIO; }
+  size_t ok = fwrite(hdr, 1, (size_t)n, out) == (size_t)n;
+  ok &= fwrite(fl.pair, sizeof(jur_int2), (size_t)tb->ng * tb->nd, out) == (size_t)tb->ng * tb->nd;
+  ok &= fwrite(fl.lvl, sizeof(jur_lvl_t), fl.nlevel, out) == (size_t)fl.nlevel;
+  ok &= fwrite(fl.crv, sizeof(jur_crv_t), fl.ncurve, out) == (size_t)fl.ncurve;
+  ok &= fwrite(fl.ue, sizeof(jur_ue_t), fl.nentry, out) == (size_t)fl.nentry;
+  ok &= fwrite(tb->sr, sizeof(double), (size_t)JUR_TBLNS * tb->nd, out) == (size_t)JUR_TBLNS * tb->nd;
+  unsigned long long const sum = jur_tables_checksum(tb);
+  ok &= fwrite(&sum, sizeof sum, 1, out) == 1;
+  ok &= fclose(out) == 0;
+  free(hdr);
+  jur_flat_free(&fl);
+  if (!ok) { jur_set_error("short write on table cache %s", path); return JUR_EIO; }
+  return JUR_OK;
+}
+
+/* JUR_OK: *out holds the tables.  JUR_EIO: no such file / unreadable.  JUR_EINVAL: the file
+ * belongs to other emitters, channels or dimensions, or is damaged (checksum). */
+int jur_tables_load(jur_tables_t **out, ctl_t const *ctl, char const *path) {
+  *out = NULL;
+  FILE *in = fopen(path, "rb");
+  if (!in) { jur_set_error("no table cache %s", path); return JUR_EIO; }
+  size_t const hlen = 256 + 64 * ((size_t)ctl->ng + ctl->nd) + (size_t)ctl->ng * JUR_LEN;
+  char *want = (char *)malloc(hlen), *have = (char *)malloc(hlen);
+  jur_flat_t fl;
+  memset(&fl, 0, sizeof fl);
+  jur_tables_t *tb = NULL;
+  int rc = JUR_EINVAL;
+  /* the header is plain text; everything but the three counts must be what this ctl would write */
+  int const n0 = cache_header(want, hlen, ctl, NULL);
+  if (n0 < 0 || !have) goto fail;
+  {
+    size_t got = 0;
+    int lines = 0, need = 9 + ctl->ng + ctl->nd;   /* magic, version, ng, nd, 3 counts, tblns, emitters, channels, header_end */
+    while (got + 1 < hlen && lines < need) {
+      int const ch = fgetc(in);
+      if (ch == EOF) goto fail;
+      have[got++] = (char)ch;
+      if (ch == '\n') lines++;
+    }
+    have[got] = 0;
+    long nl = -1, nc = -1, ne = -1;
+    char const *p1 = strstr(have, "nlevel "), *p2 = strstr(have, "ncurve "), *p3 = strstr(have, "nentry ");
+    if (!p1 || !p2 || !p3 || sscanf(p1, "nlevel %ld", &nl) != 1 || sscanf(p2, "ncurve %ld", &nc) != 1 ||
+        sscanf(p3, "nentry %ld", &ne) != 1 || nl < 0 || nc < 0 || ne < 0) goto mismatch;
+    fl.nlevel = nl; fl.ncurve = nc; fl.nentry = ne;
+    if (cache_header(want, hlen, ctl, &fl) != (int)got || memcmp(want, have, got) != 0) goto mismatch;
+  }
+  {
+    size_t const npair = (size_t)ctl->ng * ctl->nd;
+    fl.pair = (jur_int2 *)malloc(sizeof(jur_int2) * (npair + 1));
+    fl.lvl = (jur_lvl_t *)malloc(sizeof(jur_lvl_t) * (fl.nlevel + 1));
+    fl.crv = (jur_crv_t *)malloc(sizeof(jur_crv_t) * (fl.ncurve + 1));
+    fl.ue = (jur_ue_t *)malloc(sizeof(jur_ue_t) * (fl.nentry + 1));
+    tb = jur_tables_new(ctl->ng, ctl->nd);
+    if (!fl.pair || !fl.lvl || !fl.crv || !fl.ue || !tb) { rc = JUR_ENOMEM; goto fail; }
+    unsigned long long sum = 0;
+    if (fread(fl.pair, sizeof(jur_int2), npair, in) != npair || fread(fl.lvl, sizeof(jur_lvl_t), fl.nlevel, in) != (size_t)fl.nlevel ||
+        fread(fl.crv, sizeof(jur_crv_t), fl.ncurve, in) != (size_t)fl.ncurve || fread(fl.ue, sizeof(jur_ue_t), fl.nentry, in) != (size_t)fl.nentry ||
+        fread(tb->sr, sizeof(double), (size_t)JUR_TBLNS * ctl->nd, in) != (size_t)JUR_TBLNS * ctl->nd ||
+        fread(&sum, sizeof sum, 1, in) != 1) goto mismatch;
+    /* rebuild the hierarchy, validating every extent and offset on the way */
+    for (size_t i = 0; i < npair; i++) {
+      int const np = fl.pair[i].a;
+      long const L0 = fl.pair[i].b;
+      if (np < 0 || np > JUR_TBLNP || L0 < 0 || L0 + np > fl.nlevel) goto mismatch;
+      jur_pair_t *pr = &tb->pair[i];
+      if (np == 0) continue;
+      pr->lv = (jur_level_t *)calloc((size_t)np, sizeof(jur_level_t));
+      if (!pr->lv) { rc = JUR_ENOMEM; goto fail; }
+      pr->np = np;
+      for (int ip = 0; ip < np; ip++) {
+        jur_lvl_t const *l = &fl.lvl[L0 + ip];
+        if (l->nt < 0 || l->nt > JUR_TBLNT || l->c0 < 0 || (long)l->c0 + l->nt > fl.ncurve) goto mismatch;
+        pr->lv[ip].p = l->p;
+        pr->lv[ip].nt = l->nt;
+        for (int it = 0; it < l->nt; it++) {
+          jur_crv_t const *c = &fl.crv[l->c0 + it];
+          if (c->nu < 0 || c->nu > JUR_TBLNU || c->e0 < 0 || (long)c->e0 + c->nu > fl.nentry) goto mismatch;
+          jur_curve_t *cv = &pr->lv[ip].cv[it];
+          cv->t = c->t;
+          cv->nu = cv->cap = c->nu;
+          cv->u = (float *)malloc(sizeof(float) * (c->nu > 0 ? c->nu : 1));
+          cv->eps = (float *)malloc(sizeof(float) * (c->nu > 0 ? c->nu : 1));
+          if (!cv->u || !cv->eps) { rc = JUR_ENOMEM; goto fail; }
+          for (int iu = 0; iu < c->nu; iu++) { cv->u[iu] = fl.ue[c->e0 + iu].u; cv->eps[iu] = fl.ue[c->e0 + iu].eps; }
+        }
+      }
+    }
+    for (int id = 0; id < ctl->nd; id++) tb->have_sr[id] = 1;
+    if (jur_tables_checksum(tb) != sum) goto mismatch;
+  }
+  fclose(in);
+  free(want); free(have);
+  jur_flat_free(&fl);
+  *out = tb;
+  return JUR_OK;
+mismatch:
+  jur_set_error("table cache %s does not match this control block (emitters, channels, dimensions) or is damaged", path);
+  rc = JUR_EINVAL;
+fail:
+  fclose(in);
+  free(want); free(have);
+  jur_flat_free(&fl);
+  jur_tables_free(tb);
+  return rc;
+}

@@ -68,8 +68,8 @@ def make_ctl(emitters, nu, tblbase="-", **kw):
     for w in range(NW):
         ctl.retk_zmin[w] = ctl.retk_zmax[w] = -999.0
     ctl.formod = 2
-    ctl.read_binary = -1
-    ctl.write_binary = 1
+    ctl.read_binary = 0      # as the example control files set them (limb.ctl:23-24); read_ctl's own
+    ctl.write_binary = 0     # defaults are -1 / 1
     for k, v in kw.items():
         setattr(ctl, k, v)
     if "ctm_auto" not in kw:

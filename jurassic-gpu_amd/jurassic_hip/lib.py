@@ -33,6 +33,11 @@ def lib():
         L.jur_tables_read_ascii.argtypes = [C.c_void_p, C.c_void_p]
         L.jur_tables_set_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp]
         L.jur_tables_read_filters.argtypes = [C.c_void_p, C.c_void_p]
+        L.jur_tables_save.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+        L.jur_tables_load.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_char_p]
+        L.jur_tables_cache_filename.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+        L.jur_tables_checksum.restype = C.c_ulonglong
+        L.jur_tables_checksum.argtypes = [C.c_void_p]
         L.jur_tables_entries.restype = C.c_long
         L.jur_tables_entries.argtypes = [C.c_void_p]
         L.jur_model_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int]
@@ -104,6 +109,20 @@ class Tables:
 
     def entries(self):
         return lib().jur_tables_entries(self.h)
+
+    def checksum(self):
+        return lib().jur_tables_checksum(self.h)
+
+    def save(self, ctl, path):
+        _chk(lib().jur_tables_save(self.h, C.byref(ctl), os.fsencode(path)))
+
+    @classmethod
+    def load(cls, ctl, path):
+        h = C.c_void_p()
+        _chk(lib().jur_tables_load(C.byref(h), C.byref(ctl), os.fsencode(path)))
+        self = cls.__new__(cls)
+        self.h, self.ng, self.nd = h, ctl.ng, ctl.nd
+        return self
 
 
 class Model:

@@ -71,6 +71,28 @@ def test_ascii_reader_counts_files(tmp_path):
     assert tb.entries() == sum(len(r) for r in case.rows.values())
 
 
+def test_table_cache_round_trip_and_rejection(tmp_path):
+    """SURVEY 8f-1: parsed tables + source functions -> compact binary cache -> identical tables;
+    a cache written for other channels, or a damaged one, is refused."""
+    case = common.limb_case(missing={(3, 0)})
+    tb = case.lib_tables()
+    path = str(tmp_path / "cache.bin")
+    tb.save(case.ctl, path)
+    assert os.path.getsize(path) < 9 * tb.entries() + 64 * 1024 + 2 * 1201 * 8
+    back = lib.Tables.load(case.ctl, path)
+    assert back.entries() == tb.entries() and back.checksum() == tb.checksum() != 0
+    other = abi.make_ctl(common.LIMB_EMITTERS, [792.0, 833.0])
+    with pytest.raises(lib.JurassicError, match="does not match"):
+        lib.Tables.load(other, path)
+    with pytest.raises(lib.JurassicError, match="no table cache"):
+        lib.Tables.load(case.ctl, path + ".missing")
+    blob = bytearray(open(path, "rb").read())
+    blob[len(blob) // 2] ^= 0x40
+    open(path, "wb").write(bytes(blob))
+    with pytest.raises(lib.JurassicError, match="does not match"):
+        lib.Tables.load(case.ctl, path)
+
+
 def test_compute_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -216,6 +216,34 @@ def test_drop_in_nadir_in_fresh_process(hip, oracle, tmp_path):
     assert out.returncode == 0 and "DROPIN_NADIR_OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_model_from_files_uses_the_binary_cache(hip, oracle, tmp_path, monkeypatch):
+    """READ_BINARY=-1 / WRITE_BINARY=1 (upstream defaults, jurassic.c:1018-1019): the first model parses
+    the ASCII tables and writes the cache into the working directory, the second one is built from the
+    cache alone (ASCII files removed) and gives bit-identical results."""
+    case = common.limb_case(read_binary=-1, write_binary=1)
+    case.write_files(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    m1 = hip.Model(case.ctl)
+    m1.set_atm(case.atm)
+    a = m1.formod_host(case.geom)
+    m1.close()
+    assert os.path.exists(tmp_path / "bin.jurassic-hip-tables-g5-d2")
+    for f in os.listdir(tmp_path):
+        if f.endswith((".tab", ".filt")):
+            os.remove(tmp_path / f)
+    m2 = hip.Model(case.ctl)
+    m2.set_atm(case.atm)
+    b = m2.formod_host(case.geom)
+    m2.close()
+    assert np.array_equal(a["rad"], b["rad"]) and np.array_equal(a["tau"], b["tau"])
+    ref = oracle.formod_rays(case.ctl, case.atm, case.oracle_tables(oracle), case.geom)
+    assert common.rel_err(a["rad"], ref["rad"]).max() < 1e-6      # ASCII round trip: %.9g text, fp32 tables
+    case.ctl.read_binary = 1
+    os.remove(tmp_path / "bin.jurassic-hip-tables-g5-d2")
+    with pytest.raises(hip.JurassicError, match="no table cache"):
+        hip.Model(case.ctl)
+
+
 def _retrieval_case(**kw):
     case = common.limb_case(**kw)
     c = case.ctl
