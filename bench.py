@@ -192,6 +192,7 @@ def main():
                                    "not the physical bound -- see traffic (PMC bytes per launch) and DESIGN.md"}
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()          # rank 0 may still have been in its CPU-side bookkeeping
         dist.destroy_process_group()
 
 

@@ -69,7 +69,8 @@ typedef struct {
  * while the workspace arrays (np, tsurf, los) are indexed by slot. */
 typedef struct {
   int n;                        /* rays in this chunk                           */
-  int stride;                   /* R: ray stride of the LOS workspace           */
+  int stride;                   /* Rt: ray stride of the LOS workspace          */
+  int stride_eps;               /* R: ray stride of the transmittance workspace */
   long first;                   /* first ray id when order == NULL              */
   int const *order;             /* [n] ray ids of this chunk, or NULL           */
   double const *geom[7];        /* time, obsz, obslon, obslat, vpz, vplon, vplat; [nr] */

@@ -137,7 +137,9 @@ __global__ void jur_pslope_kernel(int n, double const *__restrict__ z, double co
 // ---------------------------------------------------------------------------------------
 // ray tracing, one lane per ray
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void jur_trace_kernel(jur_view_t v, jur_chunk_t c) {
+// 4 waves per SIMD (128 VGPRs, some scratch): measured 20 % faster than 2 waves without spills once a
+// launch carries enough rays (>= 4 x 131072) to fill them
+__global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chunk_t c) {
   int const r = blockIdx.x * blockDim.x + threadIdx.x;   // slot in the chunk
   if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
@@ -619,10 +621,11 @@ __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t 
   int const pair_idx = g * v.nd + d;
   if (v.pair[pair_idx].a < 2) return;            // no table: transmittance 1, the combine kernel knows
   size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
+  size_t const Re = (size_t)c.stride_eps, fe = (size_t)NLOS * Re;
   // planes of the workspace are addressed as (uniform row pointer) + lane offset
   double const *const los_p = c.los + JUR_F_P * fs, *const los_t = c.los + JUR_F_T * fs,
                *const los_u = c.los + (size_t)(JUR_F_K + v.nw + g) * fs;
-  double *const out = c.eps + (size_t)pr * fs;
+  double *const out = c.eps + (size_t)pr * fe;
   int const np = c.np[r];
   double tau_path = 1.0;
   unsigned br = 0, ia = 0, ib = 0;
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t 
     double const p = ldg<double>(los_p + o, r), t = ldg<double>(los_t + o, r), u = ldg<double>(los_u + o, r);
     double const eps = ega_eps<WARM>(v, pair_idx, tau_path, t, u, p, br, ia, ib);
     tau_path *= eps;
-    *reinterpret_cast<double *>(reinterpret_cast<char *>(out + o) + (size_t)((unsigned)r * 8u)) = eps;
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)((unsigned)r * 8u)) = eps;
   }
 }
 
@@ -648,8 +651,9 @@ __global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chun
   if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
   size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
+  size_t const Re = (size_t)c.stride_eps, fe = (size_t)NLOS * Re;
   double const *const los = c.los;
-  double const *const epsb = c.eps + (size_t)d * ng * fs;
+  double const *const epsb = c.eps + (size_t)d * ng * fe;
   jur_chan_t const ch = v.chan[d];
   double const *const sr = v.sr + (size_t)d * TBLNS;
   int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chun
     if (do_o2) beta_ds += ctm_o2(ch, p, t) * ds;
     double tau_gas = 1.0;
     for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
-      if (v.pair[g * nd + d].a >= 2) tau_gas *= ldg<double>(epsb + (size_t)g * fs + o, r);
+      if (v.pair[g * nd + d].a >= 2) tau_gas *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
     double const src = planck_src(sr, t);
     if (tau_gas > 1e-50) {  // jr_common.h:293-300
       double const eps = 1. - tau_gas * exp(-beta_ds);

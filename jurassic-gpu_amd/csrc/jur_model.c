@@ -39,7 +39,10 @@ struct jur_model {
   double *d_los;
   double *d_eps;                /* segment transmittances per (channel, gas)     */
   long ws_budget;               /* bytes of workspace the model may hold         */
-  long ws_rays;                 /* R the workspace is laid out for               */
+  long ws_rays;                 /* R: rays per ega/combine launch the workspace is laid out for */
+  long ws_trace_rays;           /* Rt >= R: rays per trace launch (LOS workspace stride)        */
+  int trace_mult;               /* wanted Rt / R                                                */
+  long use_rays, use_trace_rays;/* R, Rt of the current call (<= the allocated capacities)     */
   int *d_np;
   double *d_tsurf;
   int *d_status;
@@ -56,11 +59,12 @@ struct jur_model {
   hipStream_t stream;
   /* timing */
   int timing;
-  hipEvent_t *evpool;           /* 4 events per timed chunk                      */
+  hipEvent_t *evpool;           /* 2 events per timed launch                     */
+  unsigned char *evkind;        /* 0 trace, 1 ega, 2 combine                     */
   int ntimed;
 };
 
-#define JUR_MAX_TIMED 1024
+#define JUR_MAX_TIMED 4096
 
 static int find_emitter(ctl_t const *ctl, char const *name) {
   for (int ig = 0; ig < ctl->ng; ig++)
@@ -153,7 +157,8 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   m->nfield = JUR_F_K + v->nw + v->ng;
   m->chunk_rays = 131072;
   m->sort_rays = 1;
-  m->ws_budget = 24L << 30;
+  m->ws_budget = 32L << 30;
+  m->trace_mult = 4;
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { jur_set_error("hipStreamCreate failed"); jur_model_destroy(m); return JUR_EHIP; }
   if ((rc = upload((void **)&m->d_status, NULL, sizeof(int)))) { jur_model_destroy(m); return rc; }
   HIPCHK(hipMemset(m->d_status, 0, sizeof(int)));
@@ -201,8 +206,9 @@ void jur_model_destroy(jur_model_t *m) {
     if (ptrs[i]) (void)hipFree(ptrs[i]);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   if (m->evpool) {
-    for (int i = 0; i < 4 * JUR_MAX_TIMED; i++) (void)hipEventDestroy(m->evpool[i]);
+    for (int i = 0; i < 2 * JUR_MAX_TIMED; i++) (void)hipEventDestroy(m->evpool[i]);
     free(m->evpool);
+    free(m->evkind);
   }
   free(m->ctl);
   free(m);
@@ -324,7 +330,9 @@ int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
 
 /* ---- workspace --------------------------------------------------------------- */
 static int ensure_workspace(jur_model_t *m, long nr) {
-  /* bytes per ray: LOS fields, plus one double per (channel, gas, point) */
+  /* bytes per ray: LOS fields (per traced ray), one double per (channel, gas, point) (per integrated ray).
+   * Tracing is latency-bound and wants many rays per launch, so its launches cover Rt = trace_mult * R rays
+   * while the ega/combine launches cover R. */
   long const per_ray_los = (long)sizeof(double) * m->nfield * JUR_NLOS;
   long const per_ray_eps = (long)sizeof(double) * m->view.nd * (m->view.ng > 0 ? m->view.ng : 1) * JUR_NLOS;
   long R = m->chunk_rays;
@@ -332,19 +340,26 @@ static int ensure_workspace(jur_model_t *m, long nr) {
   if (R > fit) R = fit / 64 * 64;
   if (nr < R) R = (nr + 63) / 64 * 64;
   if (R < 64) R = 64;
-  if (R > m->ws_rays) {
+  long mult = m->trace_mult > 0 ? m->trace_mult : 1;
+  while (mult > 1 && (per_ray_los * mult + per_ray_eps) * R > m->ws_budget) mult--;
+  long Rt = R * mult;
+  if (nr < Rt) Rt = (nr + R - 1) / R * R;
+  if (R > m->ws_rays || Rt > m->ws_trace_rays) {
     if (m->d_los) (void)hipFree(m->d_los);
     if (m->d_eps) (void)hipFree(m->d_eps);
     if (m->d_np) (void)hipFree(m->d_np);
     if (m->d_tsurf) (void)hipFree(m->d_tsurf);
-    m->d_los = NULL; m->d_eps = NULL; m->d_np = NULL; m->d_tsurf = NULL; m->los_bytes = 0; m->ws_rays = 0;
-    HIPCHK(hipMalloc((void **)&m->d_los, (size_t)per_ray_los * R));
+    m->d_los = NULL; m->d_eps = NULL; m->d_np = NULL; m->d_tsurf = NULL; m->los_bytes = 0; m->ws_rays = 0; m->ws_trace_rays = 0;
+    HIPCHK(hipMalloc((void **)&m->d_los, (size_t)per_ray_los * Rt));
     HIPCHK(hipMalloc((void **)&m->d_eps, (size_t)per_ray_eps * R));
-    HIPCHK(hipMalloc((void **)&m->d_np, sizeof(int) * R));
-    HIPCHK(hipMalloc((void **)&m->d_tsurf, sizeof(double) * R));
-    m->los_bytes = (per_ray_los + per_ray_eps) * R;
+    HIPCHK(hipMalloc((void **)&m->d_np, sizeof(int) * Rt));
+    HIPCHK(hipMalloc((void **)&m->d_tsurf, sizeof(double) * Rt));
+    m->los_bytes = per_ray_los * Rt + per_ray_eps * R;
     m->ws_rays = R;
+    m->ws_trace_rays = Rt;
   }
+  m->use_rays = R;
+  m->use_trace_rays = Rt;
   return JUR_OK;
 }
 
@@ -359,6 +374,12 @@ int jur_model_set_workspace_budget(jur_model_t *m, long bytes) {
   return JUR_OK;
 }
 
+int jur_model_set_trace_multiple(jur_model_t *m, int mult) {
+  if (mult < 1 || mult > 64) { jur_set_error("trace multiple must be in 1..64"); return JUR_EINVAL; }
+  m->trace_mult = mult;
+  return JUR_OK;
+}
+
 int jur_model_set_chunk_rays(jur_model_t *m, int rays) {
   if (rays < 64 || rays > (1 << 22)) { jur_set_error("chunk_rays must be in 64..4194304"); return JUR_EINVAL; }
   m->chunk_rays = (rays + 63) / 64 * 64;
@@ -368,9 +389,10 @@ int jur_model_set_chunk_rays(jur_model_t *m, int rays) {
 int jur_model_enable_timing(jur_model_t *m, int on) {
   HIPCHK(hipSetDevice(m->device));
   if (on && !m->evpool) {
-    m->evpool = (hipEvent_t *)calloc(4 * JUR_MAX_TIMED, sizeof(hipEvent_t));
-    if (!m->evpool) return JUR_ENOMEM;
-    for (int i = 0; i < 4 * JUR_MAX_TIMED; i++) HIPCHK(hipEventCreate(&m->evpool[i]));
+    m->evpool = (hipEvent_t *)calloc(2 * JUR_MAX_TIMED, sizeof(hipEvent_t));
+    m->evkind = (unsigned char *)calloc(JUR_MAX_TIMED, 1);
+    if (!m->evpool || !m->evkind) return JUR_ENOMEM;
+    for (int i = 0; i < 2 * JUR_MAX_TIMED; i++) HIPCHK(hipEventCreate(&m->evpool[i]));
   }
   m->timing = on;
   m->ntimed = 0;
@@ -385,13 +407,11 @@ int jur_model_last_kernel_ms(jur_model_t *m, double out_ms[3], long out_launches
   if (!m->evpool) return JUR_OK;
   HIPCHK(hipSetDevice(m->device));
   for (int i = 0; i < m->ntimed; i++) {
-    hipEvent_t *ev = m->evpool + 4 * i;
-    HIPCHK(hipEventSynchronize(ev[3]));
-    for (int k = 0; k < 3; k++) {
-      float ms = 0;
-      HIPCHK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-      out_ms[k] += ms; out_launches[k]++;
-    }
+    float ms = 0;
+    HIPCHK(hipEventSynchronize(m->evpool[2 * i + 1]));
+    HIPCHK(hipEventElapsedTime(&ms, m->evpool[2 * i], m->evpool[2 * i + 1]));
+    out_ms[m->evkind[i]] += ms;
+    out_launches[m->evkind[i]]++;
   }
   m->ntimed = 0;
   return JUR_OK;
@@ -408,7 +428,7 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
   int rc = ensure_workspace(m, nr);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  long const R = m->ws_rays;
+  long const R = m->use_rays;
   int const *order = NULL;
   if (m->sort_rays && nr > 64) {
     /* similar rays side by side: equal trip counts inside a wavefront and neighbouring
@@ -428,37 +448,48 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     if (e) { jur_set_error("ray sort failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
     order = m->d_order;
   }
-  for (long r0 = 0; r0 < nr; r0 += R) {
+  long const Rt = m->use_trace_rays;
+#define TIMED(kind, launch, what)                                                              \
+  do {                                                                                         \
+    int const ti_ = (m->timing && m->ntimed < JUR_MAX_TIMED) ? m->ntimed++ : -1;               \
+    if (ti_ >= 0) { m->evkind[ti_] = (kind); HIPCHK(hipEventRecord(m->evpool[2 * ti_], s)); } \
+    int const e_ = (launch);                                                                   \
+    if (e_) { jur_set_error(what " kernel launch failed: %s", hipGetErrorString((hipError_t)e_)); return JUR_EHIP; } \
+    if (ti_ >= 0) HIPCHK(hipEventRecord(m->evpool[2 * ti_ + 1], s));                          \
+  } while (0)
+  for (long t0 = 0; t0 < nr; t0 += Rt) {
     jur_chunk_t c;
-    c.n = (int)((nr - r0 < R) ? nr - r0 : R);
-    c.stride = (int)R;
-    c.first = r0;
-    c.order = order ? order + r0 : NULL;
+    long const nt = (nr - t0 < Rt) ? nr - t0 : Rt;
+    c.stride = (int)Rt;
+    c.stride_eps = (int)R;
     for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * nr;
     for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * nr;
     c.rad = d_rad;
     c.tau = d_tau;
     c.np_out = d_np;
+    c.eps = m->d_eps;
+    c.status = d_status ? d_status : m->d_status;
+    /* trace the whole super-chunk */
+    c.n = (int)nt;
+    c.first = t0;
+    c.order = order ? order + t0 : NULL;
     c.np = m->d_np;
     c.tsurf = m->d_tsurf;
     c.los = m->d_los;
-    c.eps = m->d_eps;
-    c.status = d_status ? d_status : m->d_status;
-    hipEvent_t *ev = (m->timing && m->ntimed < JUR_MAX_TIMED) ? m->evpool + 4 * m->ntimed : NULL;
-    if (ev) HIPCHK(hipEventRecord(ev[0], s));
-    int e = jurk_launch_trace(&m->view, &c, s);
-    if (e) { jur_set_error("trace kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
-    if (ev) HIPCHK(hipEventRecord(ev[1], s));
-    e = jurk_launch_ega(&m->view, &c, s);
-    if (e) { jur_set_error("ega kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
-    if (ev) HIPCHK(hipEventRecord(ev[2], s));
-    e = jurk_launch_combine(&m->view, &c, s);
-    if (e) { jur_set_error("combine kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
-    if (ev) {
-      HIPCHK(hipEventRecord(ev[3], s));
-      m->ntimed++;
+    TIMED(0, jurk_launch_trace(&m->view, &c, s), "trace");
+    /* integrate it in chunks of R rays; slot s0 of the super-chunk is slot 0 of the chunk */
+    for (long s0 = 0; s0 < nt; s0 += R) {
+      c.n = (int)((nt - s0 < R) ? nt - s0 : R);
+      c.first = t0 + s0;
+      c.order = order ? order + t0 + s0 : NULL;
+      c.np = m->d_np + s0;
+      c.tsurf = m->d_tsurf + s0;
+      c.los = m->d_los + s0;
+      TIMED(1, jurk_launch_ega(&m->view, &c, s), "ega");
+      TIMED(2, jurk_launch_combine(&m->view, &c, s), "combine");
     }
   }
+#undef TIMED
   return JUR_OK;
 }
 

@@ -51,6 +51,7 @@ def lib():
         L.jur_model_chunk_rays.argtypes = [C.c_void_p]
         L.jur_model_set_chunk_rays.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_set_sort_rays.argtypes = [C.c_void_p, C.c_int]
+        L.jur_model_set_trace_multiple.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_set_workspace_budget.argtypes = [C.c_void_p, C.c_long]
         L.jur_model_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_last_kernel_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
@@ -153,6 +154,9 @@ class Model:
 
     def set_sort_rays(self, on):
         _chk(lib().jur_model_set_sort_rays(self.h, int(on)))
+
+    def set_trace_multiple(self, mult):
+        _chk(lib().jur_model_set_trace_multiple(self.h, mult))
 
     def set_workspace_budget(self, nbytes):
         _chk(lib().jur_model_set_workspace_budget(self.h, nbytes))
