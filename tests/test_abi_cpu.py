@@ -93,6 +93,25 @@ def test_table_cache_round_trip_and_rejection(tmp_path):
         lib.Tables.load(case.ctl, path)
 
 
+def test_formod_executable_parses_control_file_and_overrides(tmp_path):
+    """scan_ctl semantics (jurassic.c:1153-1201): KEY = VALUE lines, KEY[i] / KEY[*], command-line
+    overrides, defaults, the automatic continuum switch-off; CHECKMODE keeps the GPU out of it."""
+    import subprocess
+    exe = os.path.join(ROOT, "jurassic-gpu_amd", "formod")
+    assert os.path.exists(exe)
+    (tmp_path / "t.ctl").write_text("NG = 1\nEMITTER[0] = CO2\nND = 2\nNU[*] = 700\nTBLBASE = ./x\n")
+    out = subprocess.run([exe, "t.ctl", os.path.join(common.GOLD, "nadir", "obs.tab"),
+                          os.path.join(common.GOLD, "nadir", "atm.tab"), "rad.tab", "CHECKMODE", "1", "RAYDS", "5"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for line in ("NG = 1", "ND = 2", "RAYDS = 5", "RAYDZ = 0.5", "REFRAC = 1", "CTM_CO2 = 1", "READ_BINARY = -1",
+                 "No frequency in N2 range, automatically set CTM_N2 = 0", "CHECKMODE = 1 (skip)"):
+        assert line in out.stdout, line
+    assert not (tmp_path / "rad.tab").exists()
+    bad = subprocess.run([exe, "t.ctl", "a", "b", "c", "NG", "2"], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and "Missing variable EMITTER[1]" in bad.stdout
+
+
 def test_compute_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -244,6 +244,55 @@ def test_model_from_files_uses_the_binary_cache(hip, oracle, tmp_path, monkeypat
         hip.Model(case.ctl)
 
 
+LIMB_CTL = """# Forward model...
+TBLBASE = ./boxcar
+NG = 5
+EMITTER[0] = CO2
+EMITTER[1] = H2O
+EMITTER[2] = O3
+EMITTER[3] = F11
+EMITTER[4] = CCl4
+ND = 2
+NU[0] = 792.0000
+NU[1] = 832.0000
+USEGPU = -1
+WRITE_BINARY = 0
+READ_BINARY = 0
+"""
+
+
+def test_formod_executable_end_to_end(hip, oracle, tmp_path):
+    """`formod <ctl> <obs> <atm> <rad>` as example/limb/run.sh calls it (control file with
+    the keys of example/limb/limb.ctl, the shipped obs.tab / atm.tab / .filt files, a command-line
+    override).  The geometry columns of the written table equal the reference's rad.org as text."""
+    case = common.limb_case()
+    for d, nu in enumerate(common.LIMB_NU):
+        case.filters[d] = tuple(np.loadtxt(os.path.join(common.GOLD, "limb", "boxcar_%.4f.filt" % nu), comments="#").T)
+    case.write_files(str(tmp_path), base="boxcar")
+    (tmp_path / "limb.ctl").write_text(LIMB_CTL)
+    exe = os.path.join(common.ROOT, "jurassic-gpu_amd", "formod")
+    out = subprocess.run([exe, "limb.ctl", os.path.join(common.GOLD, "limb", "obs.tab"),
+                          os.path.join(common.GOLD, "limb", "atm.tab"), "rad.tab", "REFRAC", "1"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = [l.split() for l in open(tmp_path / "rad.tab") if l.strip() and not l.startswith("#")]
+    gold = [l.split() for l in open(os.path.join(common.GOLD, "limb", "rad.org")) if l.strip() and not l.startswith("#")]
+    assert len(got) == len(gold) == 66
+    for a, b in zip(got, gold):
+        assert a[:8] == b[:8] and a[9] == b[9]                  # time .. tpz, tplat: text-identical
+        assert abs(float(a[8]) - float(b[8])) < 1e-11           # tplon is atan2 noise
+    header = [l for l in open(tmp_path / "rad.tab") if l.startswith("#")]
+    assert header == [l for l in open(os.path.join(common.GOLD, "limb", "rad.org")) if l.startswith("#")]
+    # radiance / transmittance columns against the oracle fed with the same files
+    case.ctl.tblbase = os.path.join(str(tmp_path), "boxcar").encode()
+    tb = oracle.Tables(5, 2)
+    assert tb.read_ascii(case.ctl) == 0 and tb.planck_filt(case.ctl) == 0
+    ref = oracle.formod_rays(case.ctl, case.atm, tb, case.geom)
+    mine = np.array([[float(x) for x in row[10:14]] for row in got])
+    want = np.hstack([ref["rad"], ref["tau"]])
+    assert np.max(np.abs(mine - want) / np.abs(want)) < 1e-5    # %g keeps 6 significant digits
+
+
 def _retrieval_case(**kw):
     case = common.limb_case(**kw)
     c = case.ctl
