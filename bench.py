@@ -85,7 +85,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the library has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ        # under torchrun the RCCL path runs even at N = 1
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     nrays = args.rays or (1_000_000 if args.workload == "limb_1e6" else 100_000)
@@ -102,18 +103,18 @@ def main():
     d_tp = torch.zeros((3, nrays), dtype=torch.float64, device=dev)
     d_np = torch.zeros(nrays, dtype=torch.int32, device=dev)
     d_status = torch.zeros(1, dtype=torch.int32, device=dev)
-    gathered = [torch.empty_like(d_rad) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty_like(d_rad) for _ in range(world)] if (use_dist and rank == 0) else None
 
     def step():
         d_rad.zero_()          # input rad carries the NaN mask; all finite here
         stream = torch.cuda.current_stream().cuda_stream
         model.formod_device(nrays, d_geom.data_ptr(), d_rad.data_ptr(), d_tau.data_ptr(), d_tp.data_ptr(),
                             d_np.data_ptr(), d_status.data_ptr(), stream)
-        if world > 1:
-            dist.gather(d_rad, gathered, dst=0)
+        if use_dist:
+            dist.gather(d_rad, gathered, dst=0)      # per-detector radiances to rank 0 over xGMI (RCCL)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -134,8 +135,10 @@ def main():
         raise SystemExit("non-finite radiance in the benchmark output")
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if use_dist and rank == 0 and not torch.equal(gathered[0], d_rad):
+        raise SystemExit("gathered radiances differ from the local ones")
     dt = float(t.item())
 
     if rank == 0:
@@ -191,7 +194,7 @@ def main():
                                    "cache-resident and searches warm-started, so frac > 1 is possible and HBM is "
                                    "not the physical bound -- see traffic (PMC bytes per launch) and DESIGN.md"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()          # rank 0 may still have been in its CPU-side bookkeeping
         dist.destroy_process_group()
 
