@@ -291,65 +291,19 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
       double n = 1., ngr[3] = {0., 0., 0.};
       if (v.refrac && z <= 60.) {  // refractivity gradient by finite differences (:665-681)
         n += refractivity(p, t);
-        double const h = 0.02;
-        // the four probe positions exactly as the reference's in-place `xh[i] += h; ...; xh[i] -= h` leaves them
-        double xh[3], pos[4][3];
+        double xh[3], zz, llon, llat, pp, tt;
         for (int i = 0; i < 3; i++) xh[i] = x[i] + 0.5 * ds * ex0[i];
-        for (int i = 0; i < 3; i++) pos[0][i] = xh[i];
-        for (int k = 0; k < 3; k++) {
-          xh[k] += h;
-          for (int i = 0; i < 3; i++) pos[k + 1][i] = xh[i];
-          xh[k] -= h;
+        cart2geo(xh, zz, llon, llat);
+        intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
+        double const n2 = refractivity(pp, tt);
+        for (int i = 0; i < 3; i++) {
+          double const h = 0.02;
+          xh[i] += h;
+          cart2geo(xh, zz, llon, llat);
+          intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
+          ngr[i] = (refractivity(pp, tt) - n2) / h;
+          xh[i] -= h;
         }
-        double rf[4];
-        if (zdir != 0) {
-          // the probes lie within RAYDZ/2 + h of this point's altitude: their brackets are this point's
-          // bracket or a neighbour.  One predicated step each, all four evaluated side by side
-          // (independent exp/divide chains); a probe whose bracket is further away takes the walk.
-          double const *const az = v.atm_z + atm0, *const ap = v.atm_p + atm0, *const at = v.atm_t + atm0,
-                       *const as = v.atm_pslope + atm0;
-          int const i0 = ia - atm0;
-          double zq[4];
-          int iq[4];
-          bool ok = true;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            zq[k] = norm3(pos[k]) - JUR_RE;
-            int i = i0;
-            double const zl = az[i], zh = az[i + 1];
-            int const dn = (zdir > 0) ? (zl > zq[k]) : (zl <= zq[k]);
-            int const up = (zdir > 0) ? !(zh > zq[k]) : !(zh <= zq[k]);
-            i += ((i < atmn - 2) & up) - ((i > 0) & dn);
-            iq[k] = i;
-          }
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            int const i = iq[k];
-            double const za = az[i], zb = az[i + 1];
-            bool const lo_ok = (i == 0) || ((zdir > 0) ? !(za > zq[k]) : !(za <= zq[k]));
-            bool const hi_ok = (i == atmn - 2) || ((zdir > 0) ? (zb > zq[k]) : (zb <= zq[k]));
-            ok = ok && lo_ok && hi_ok;
-            double const sl = as[i];
-            double const pp = (sl == sl) ? ap[i] * exp(sl * (zq[k] - za)) : lip(za, ap[i], zb, ap[i + 1], zq[k]);
-            double const tt = lip(za, at[i], zb, at[i + 1], zq[k]);
-            rf[k] = refractivity(pp, tt);
-          }
-          if (!ok) {  // rare: a profile finer than the probe offsets
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              double pp, tt;
-              intpol_pt(v, atm0, atmn, zq[k], pp, tt, zdir, rhint);
-              rf[k] = refractivity(pp, tt);
-            }
-          }
-        } else {
-          for (int k = 0; k < 4; k++) {
-            double pp, tt;
-            intpol_pt(v, atm0, atmn, norm3(pos[k]) - JUR_RE, pp, tt, zdir, rhint);
-            rf[k] = refractivity(pp, tt);
-          }
-        }
-        for (int i = 0; i < 3; i++) ngr[i] = (rf[i + 1] - rf[0]) / h;
       }
       double ex1[3];
       for (int i = 0; i < 3; i++) ex1[i] = ex0[i] * n + ds * ngr[i];
