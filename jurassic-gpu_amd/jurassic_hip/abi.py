@@ -5,7 +5,13 @@ reference's src/jurassic.h:215-226 (atm_t), :229-347 (ctl_t), :371-385 (obs_t).
 """
 import ctypes as C
 
-ND, NG, NP, NR, NW, LEN, NLOS = 100, 30, 9600, 1088, 1, 5000, 400
+import os
+
+# ND / NG are compile-time dimensions of the C side (reference src/jurassic.h:138-145); a library built with
+# other values (make JUR_ND=... JUR_NG=... SUFFIX=...) is used by exporting the same numbers before import.
+ND = int(os.environ.get("JUR_ND", "100"))
+NG = int(os.environ.get("JUR_NG", "30"))
+NP, NR, NW, LEN, NLOS = 9600, 1088, 1, 5000, 400
 TBLNP, TBLNT, TBLNU, TBLNS = 40, 30, 304, 1201
 
 d = C.c_double
@@ -39,7 +45,7 @@ class obs_t(C.Structure):
                 ("tau", (d * ND) * NR), ("rad", (d * ND) * NR), ("nr", i)]
 
 
-assert C.sizeof(ctl_t) == 321856 and C.sizeof(atm_t) == 2841608 and C.sizeof(obs_t) == 1827848
+assert (ND, NG) != (100, 30) or (C.sizeof(ctl_t), C.sizeof(atm_t), C.sizeof(obs_t)) == (321856, 2841608, 1827848)
 
 
 def make_ctl(emitters, nu, tblbase="-", **kw):

@@ -9,7 +9,8 @@ import numpy as np
 from . import abi
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.environ.get("JURASSIC_HIP_SO", os.path.join(PKG, "libjurassic_hip.so"))   # override: A/B builds only
+SO = os.environ.get("JURASSIC_HIP_SO",       # override: A/B builds
+                    os.path.join(PKG, "libjurassic_hip%s.so" % os.environ.get("JUR_SUFFIX", "")))
 _lib = None
 dp = C.POINTER(C.c_double)
 

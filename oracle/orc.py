@@ -18,14 +18,17 @@ _lib = None
 dp = C.POINTER(C.c_double)
 
 
+SUFFIX = os.environ.get("JUR_SUFFIX", "")      # dimension variant, e.g. _nd2378 with JUR_ND / JUR_NG exported
+
+
 def build():
-    subprocess.check_call(["make", "-s", "-C", HERE])
+    subprocess.check_call(["make", "-s", "-C", HERE, "JUR_ND=%d" % abi.ND, "JUR_NG=%d" % abi.NG, "SUFFIX=" + SUFFIX])
 
 
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(HERE, "liboracle.so")
+        path = os.path.join(HERE, "liboracle%s.so" % SUFFIX)
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -182,6 +182,42 @@ def test_hundred_channels_three_gases(hip, oracle):
     assert_parity(out, ref)
 
 
+WIDE = r"""
+import os, sys
+sys.path[:0] = [{root!r}, os.path.join({root!r}, 'jurassic-gpu_amd'), os.path.join({root!r}, 'tests')]
+import numpy as np, common
+from oracle import orc
+from jurassic_hip import abi, lib, synth
+assert (abi.ND, abi.NG) == (2378, 3)
+out = (__import__('ctypes').c_size_t * 5)()
+lib.lib().jur_abi_sizes(out)
+assert list(out)[3:] == [2378, 3] and out[0] == __import__('ctypes').sizeof(abi.ctl_t) and out[2] == __import__('ctypes').sizeof(abi.obs_t)
+nu = [650.0 + i * (2665.0 - 650.0) / 2377 for i in range(2378)]           # SURVEY 8d, C5
+geom = np.vstack([synth.nadir_geometry(48, seed=5), synth.limb_geometry(16, seed=6)])
+case = common.Case(["CO2", "H2O", "O3"], nu, os.path.join(common.GOLD, "limb", "atm.tab"), geom,
+                   table_kw=dict(nlev=12, ntemp=4), write_bbt=0)
+model = lib.Model(case.ctl, case.lib_tables())
+model.set_atm(case.atm)
+got = model.formod_host(case.geom)
+ref = orc.formod_rays(case.ctl, case.atm, case.oracle_tables(orc), case.geom)
+assert np.array_equal(got['np'], ref['np'])
+assert np.max(np.abs(got['rad'] - ref['rad']) / np.abs(ref['rad'])) < 1e-9
+assert np.all(np.abs(got['tau'] - ref['tau']) <= 1e-9 * np.abs(ref['tau']) + 1e-13)
+print('WIDE_OK', got['rad'].shape)
+"""
+
+
+def test_2378_channel_build(hip, oracle, tmp_path):
+    """BASELINE configs[4] shape: library and oracle rebuilt with the reference's compile-time
+    dimensions ND=2378, NG=3 (jurassic.h:138-145), 2378 channels x 3 emitters = 7134 tables,
+    nadir and limb rays.  Runs in its own process because the dimensions are fixed at import."""
+    script = tmp_path / "wide.py"
+    script.write_text(WIDE.format(root=common.ROOT))
+    env = dict(os.environ, JUR_ND="2378", JUR_NG="3", JUR_SUFFIX="_nd2378")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0 and "WIDE_OK (64, 2378)" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 DROPIN_NADIR = r"""
 import os, sys
 sys.path[:0] = [{root!r}, os.path.join({root!r}, 'jurassic-gpu_amd'), os.path.join({root!r}, 'tests')]
