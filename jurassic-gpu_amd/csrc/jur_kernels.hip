@@ -377,7 +377,7 @@ static_assert(sizeof(Lvl) == sizeof(jur_lvl_t) && sizeof(Crv) == sizeof(jur_crv_
 
 // Table element access as (wave-uniform base pointer) + (32-bit byte offset): the address is
 // formed by the memory instruction itself (SGPR base + VGPR offset) instead of 64-bit vector
-// arithmetic per load.  Offsets fit 32 bits: the host refuses tables beyond 2^28 entries.
+// arithmetic per load.  Offsets fit 32 bits: the host refuses tables beyond 2^29 entries.
 template <class T>
 __device__ __forceinline__ T ldg(void const *__restrict__ base, unsigned index) {
   return *reinterpret_cast<T const *>(static_cast<char const *>(base) + (size_t)(index * (unsigned)sizeof(T)));

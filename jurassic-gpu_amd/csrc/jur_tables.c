@@ -315,7 +315,7 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
       for (int it = 0; it < tb->pair[i].lv[ip].nt; it++) nentry += tb->pair[i].lv[ip].cv[it].nu;
     }
   }
-  if (nentry >= (1L << 28) || ncurve >= (1L << 27) || nlevel >= (1L << 27)) {  /* kernels address with 32-bit byte offsets */
+  if (nentry >= (1L << 29) - 4 || ncurve >= (1L << 27) || nlevel >= (1L << 27)) {  /* kernels address with 32-bit byte offsets */
     jur_set_error("tables too large for 32-bit byte offsets (%ld entries)", nentry);
     return JUR_EINVAL;
   }
