@@ -115,6 +115,11 @@ size_t jur_state_size(jur_model_t const *m, atm_t const *atm);
 size_t jur_measurement_size(jur_model_t const *m, obs_t const *obs);
 int    jur_kernel(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t mrows, size_t ncols);
 
+/* Allocate the workspace for calls of up to nr rays now.  jur_formod_device allocates lazily on
+ * first use; after jur_model_reserve (or one call of the same size) it only enqueues kernels on
+ * the stream -- no allocation, no host synchronisation -- and can be captured into a HIP graph. */
+int  jur_model_reserve(jur_model_t *m, long nr);
+
 /* Bytes of device workspace the model holds for `nr` rays per call, and the
  * chunk size (rays per kernel launch) it uses. */
 long jur_model_workspace_bytes(jur_model_t const *m);

@@ -417,6 +417,29 @@ int jur_model_last_kernel_ms(jur_model_t *m, double out_ms[3], long out_launches
   return JUR_OK;
 }
 
+static int ensure_sort_buffers(jur_model_t *m, long nr) {
+  long const need = jurk_sort_tmp_bytes(nr);
+  if (nr > m->order_cap || need > m->sort_tmp_bytes) {
+    if (m->d_order) (void)hipFree(m->d_order);
+    if (m->d_sort_tmp) (void)hipFree(m->d_sort_tmp);
+    m->d_order = NULL; m->d_sort_tmp = NULL; m->order_cap = 0; m->sort_tmp_bytes = 0;
+    HIPCHK(hipMalloc((void **)&m->d_order, sizeof(int) * (size_t)nr));
+    HIPCHK(hipMalloc(&m->d_sort_tmp, (size_t)need));
+    m->order_cap = nr; m->sort_tmp_bytes = need;
+  }
+  return JUR_OK;
+}
+
+/* Allocate everything a later jur_formod_device(m, nr, ...) needs, so that the call itself only
+ * enqueues kernels (it can then be captured into a HIP graph). */
+int jur_model_reserve(jur_model_t *m, long nr) {
+  if (!m || nr < 1 || nr > 0x7fffffffL) { jur_set_error("reserve: bad ray count"); return JUR_EINVAL; }
+  HIPCHK(hipSetDevice(m->device));
+  int rc = ensure_workspace(m, nr);
+  if (rc == JUR_OK && m->sort_rays && nr > 64) rc = ensure_sort_buffers(m, nr);
+  return rc;
+}
+
 /* ---- forward model ------------------------------------------------------------ */
 int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_rad, double *d_tau, double *d_tp,
                       int *d_np, int *d_status, void *stream) {
@@ -433,15 +456,8 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
   if (m->sort_rays && nr > 64) {
     /* similar rays side by side: equal trip counts inside a wavefront and neighbouring
      * table/profile addresses across its lanes */
-    long const need = jurk_sort_tmp_bytes(nr);
-    if (nr > m->order_cap || need > m->sort_tmp_bytes) {
-      if (m->d_order) (void)hipFree(m->d_order);
-      if (m->d_sort_tmp) (void)hipFree(m->d_sort_tmp);
-      m->d_order = NULL; m->d_sort_tmp = NULL; m->order_cap = 0; m->sort_tmp_bytes = 0;
-      HIPCHK(hipMalloc((void **)&m->d_order, sizeof(int) * (size_t)nr));
-      HIPCHK(hipMalloc(&m->d_sort_tmp, (size_t)need));
-      m->order_cap = nr; m->sort_tmp_bytes = need;
-    }
+    rc = ensure_sort_buffers(m, nr);
+    if (rc) return rc;
     /* group by atmosphere slice when every slice is used by many rays */
     int const by_profile = m->atm_slices > 1 && nr >= 1024L * m->atm_slices;
     int const e = jurk_sort_rays(&m->view, by_profile, nr, d_geom, m->d_order, m->d_sort_tmp, m->sort_tmp_bytes, s);

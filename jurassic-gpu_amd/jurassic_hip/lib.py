@@ -47,6 +47,7 @@ def lib():
         L.jur_model_set_atm.argtypes = [C.c_void_p, C.c_void_p]
         L.jur_formod_host.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
         L.jur_formod_device.argtypes = [C.c_void_p, C.c_long] + [C.c_void_p] * 7
+        L.jur_model_reserve.argtypes = [C.c_void_p, C.c_long]
         L.jur_model_workspace_bytes.restype = C.c_long
         L.jur_model_workspace_bytes.argtypes = [C.c_void_p]
         L.jur_model_chunk_rays.argtypes = [C.c_void_p]
@@ -155,6 +156,9 @@ class Model:
 
     def set_sort_rays(self, on):
         _chk(lib().jur_model_set_sort_rays(self.h, int(on)))
+
+    def reserve(self, nr):
+        _chk(lib().jur_model_reserve(self.h, nr))
 
     def set_trace_multiple(self, mult):
         _chk(lib().jur_model_set_trace_multiple(self.h, mult))

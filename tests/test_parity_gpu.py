@@ -441,6 +441,39 @@ def test_device_pointer_entry_matches_host_entry(hip):
     model.close()
 
 
+def test_device_entry_can_be_captured_in_a_graph(hip):
+    """After jur_model_reserve the device entry only enqueues kernels: capture it into a HIP graph
+    (through torch.cuda.graph on a side stream) and replay it on new inputs."""
+    import torch
+    case = common.limb_case(geom=synth.limb_geometry(1088, seed=12))
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    dev = torch.device("cuda", 0)
+    nr, nd = len(case.geom), case.ctl.nd
+    d_geom = torch.from_numpy(np.ascontiguousarray(case.geom.T)).to(dev)
+    d_rad = torch.zeros((nr, nd), dtype=torch.float64, device=dev)
+    d_tau = torch.zeros((nr, nd), dtype=torch.float64, device=dev)
+    d_tp = torch.zeros((3, nr), dtype=torch.float64, device=dev)
+    d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+    model.reserve(nr)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        d_rad.zero_()
+        model.formod_device(nr, d_geom.data_ptr(), d_rad.data_ptr(), d_tau.data_ptr(), d_tp.data_ptr(), 0,
+                            d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    graph.replay()
+    torch.cuda.synchronize()
+    first = model.formod_host(case.geom)
+    assert np.array_equal(d_rad.cpu().numpy(), first["rad"]) and np.array_equal(d_tau.cpu().numpy(), first["tau"])
+    other = synth.limb_geometry(nr, seed=13)                 # same buffers, new geometry, replay only
+    d_geom.copy_(torch.from_numpy(np.ascontiguousarray(other.T)))
+    graph.replay()
+    torch.cuda.synchronize()
+    second = model.formod_host(other)
+    assert np.array_equal(d_rad.cpu().numpy(), second["rad"]) and int(d_st.item()) == 0
+    model.close()
+
+
 def test_nlos_overflow_is_reported(hip):
     """Upstream aborts with 'Too many LOS points!' (jr_common.h:693-695)."""
     case = common.limb_case(geom=synth.limb_geometry(64, scan=True), raydz=0.2)
