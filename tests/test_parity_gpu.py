@@ -127,6 +127,47 @@ def test_table_shapes(hip, oracle, kw):
     assert_parity(out, ref)
 
 
+def _random_case(seed):
+    """Random small configuration: emitters, channels, table shapes (levels, temperatures, grid ratio,
+    curve end), missing tables, perturbed atmosphere, mixed geometries, control switches."""
+    rng = np.random.default_rng(seed)
+    ng = int(rng.integers(1, 6))
+    nd = int(rng.integers(1, 7))
+    emitters = list(rng.permutation(common.LIMB_EMITTERS)[:ng])
+    nu = sorted(float(x) for x in np.round(rng.uniform(650.0, 2600.0, nd), 4))
+    missing = {(g, d) for g in range(ng) for d in range(nd) if rng.random() < 0.15}
+    kw = dict(nlev=int(rng.integers(2, 9)), ntemp=int(rng.integers(2, 7)), ratio=float(rng.uniform(1.06, 2.2)),
+              umax_eps=float(rng.choice([0.5, 0.9, 0.999, 0.99999])))
+    nlimb, nnadir, nin = int(rng.integers(20, 120)), int(rng.integers(0, 60)), int(rng.integers(0, 20))
+    geom = [synth.limb_geometry(nlimb, seed=seed, zmin=float(rng.uniform(-10, 10)), zmax=float(rng.uniform(20, 80)))]
+    if nnadir:
+        geom.append(synth.nadir_geometry(nnadir, seed=seed + 1, lat0=-40.0, lat1=40.0))
+    for _ in range(nin):                               # observer inside the atmosphere, arbitrary view point
+        geom.append(np.array([[0, rng.uniform(1, 80), rng.uniform(-5, 5), rng.uniform(-5, 5),
+                               rng.uniform(0, 85), rng.uniform(-5, 5), rng.uniform(-5, 5)]]))
+    switches = dict(refrac=int(rng.integers(0, 2)), write_bbt=int(rng.integers(0, 2)),
+                    rayds=float(rng.choice([10.0, 20.0])), raydz=float(rng.choice([0.5, 1.0])),
+                    ctm_co2=int(rng.integers(0, 2)), ctm_h2o=int(rng.integers(0, 2)), ctm_auto=1)
+    if rng.random() < 0.3:
+        switches["hydz"] = float(rng.uniform(5, 30))
+    case = common.Case(emitters, nu, os.path.join(common.GOLD, "limb", "atm.tab"), np.vstack(geom),
+                       nprofiles=int(rng.integers(1, 5)), table_kw=kw, missing=missing, **switches)
+    n = case.atm.np                                    # reshuffle the gas columns of the shipped profile
+    q = np.ctypeslib.as_array(case.atm.q)
+    base = q[:5, :n].copy()
+    for g, em in enumerate(emitters):
+        q[g, :n] = base[common.LIMB_EMITTERS.index(em)] * rng.uniform(0.5, 2.0)
+    np.ctypeslib.as_array(case.atm.k)[0, :n] = rng.uniform(0, 1e-4)
+    case.geom[:, 0] = rng.integers(0, max(1, case.atm.np // 91), len(case.geom))   # random profile per ray
+    return case
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations(hip, oracle, seed):
+    out, ref = run_both(hip, oracle, _random_case(100 + seed))
+    assert_parity(out, ref)
+
+
 def _obs_from_geom(geom, nd):
     obs = abi.obs_t()
     obs.nr = len(geom)
