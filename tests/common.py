@@ -26,7 +26,8 @@ class Case:
             for d, v in enumerate(nu):
                 if (g, d) in missing:
                     continue
-                self.rows[(g, d)] = synth.table_rows(em, v, id_=d, **kw)
+                pkw = kw(g, d) if callable(kw) else kw          # per-pair table shapes when given a function
+                self.rows[(g, d)] = synth.table_rows(em, v, id_=d, **pkw)
         self.filters = [filt(v) if filt else synth.boxcar_filter(v) for v in nu]
 
     def oracle_tables(self, orc):

@@ -127,6 +127,28 @@ def test_table_shapes(hip, oracle, kw):
     assert_parity(out, ref)
 
 
+def test_heterogeneous_tables(hip, oracle):
+    """Every (gas, channel) pair with its own pressure/temperature axes and grid ratio, and curves that
+    degenerate to a single entry scattered through otherwise normal tables (the `nu < 2` early-out of
+    ega_eps, jr_common.h:244-246, taken for some brackets only)."""
+    shapes = [dict(nlev=33, ntemp=10), dict(nlev=7, ntemp=3, ratio=1.5), dict(nlev=12, ntemp=6, ratio=1.3),
+              dict(nlev=40, ntemp=2, ratio=1.2), dict(nlev=5, ntemp=9, ratio=2.0, umax_eps=0.9)]
+    case = common.limb_case(geom=synth.limb_geometry(300, seed=31), nu=common.CTM4_NU, nprofiles=3,
+                            table_kw=lambda g, d: shapes[(2 * g + d) % len(shapes)])
+    for (g, d), r in list(case.rows.items()):
+        if (g + d) % 2:
+            continue
+        keep = np.ones(len(r), dtype=bool)                       # thin every 7th curve down to its first row
+        start = np.flatnonzero(np.r_[True, (np.diff(r[:, 0]) != 0) | (np.diff(r[:, 1]) != 0)])
+        for k, s0 in enumerate(start):
+            s1 = start[k + 1] if k + 1 < len(start) else len(r)
+            if k % 7 == 3:
+                keep[s0 + 1:s1] = False
+        case.rows[(g, d)] = r[keep]
+    out, ref = run_both(hip, oracle, case)
+    assert_parity(out, ref)
+
+
 def _random_case(seed):
     """Random small configuration: emitters, channels, table shapes (levels, temperatures, grid ratio,
     curve end), missing tables, perturbed atmosphere, mixed geometries, control switches."""
