@@ -128,10 +128,10 @@ int  jur_model_chunk_rays(jur_model_t const *m);
  * geometric tangent altitude (default on; results do not depend on it). */
 int  jur_model_set_chunk_rays(jur_model_t *m, int rays);
 int  jur_model_set_sort_rays(jur_model_t *m, int on);
-/* Rays per ray-tracing launch as a multiple of the rays per integration launch (default 4). */
+/* Rays per ray-tracing launch as a multiple of the rays per integration launch (default 1). */
 int  jur_model_set_trace_multiple(jur_model_t *m, int mult);
 /* Upper bound of the per-call device workspace (LOS state + per-segment gas
- * transmittances); the rays-per-chunk shrink to fit.  Default 32 GiB. */
+ * transmittances); the rays-per-chunk shrink to fit.  Default 128 GiB of the 288 GB. */
 int  jur_model_set_workspace_budget(jur_model_t *m, long bytes);
 
 /* Summed duration in ms and launch count of each kernel since the last query,
