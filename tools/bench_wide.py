@@ -26,7 +26,7 @@ for g, em in enumerate(["CO2", "H2O", "O3"]):
 t_tab = time.perf_counter() - t0
 model = lib.Model(ctl, tb)
 model.set_atm(atm)
-model.formod_host(geom[:256])
+model.formod_host(geom)                  # warm-up at full size: workspace allocation happens here
 model.enable_timing(True)
 t0 = time.perf_counter()
 res = model.formod_host(geom)
