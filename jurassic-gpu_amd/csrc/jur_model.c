@@ -25,6 +25,7 @@
 
 struct jur_model {
   int device;
+  int shared_tables;            /* 1: a lane of the drop-in entry; the table arrays belong to another model */
   ctl_t *ctl;                   /* private copy of the control block             */
   jur_view_t view;              /* device pointers                               */
   long table_bytes;
@@ -204,6 +205,7 @@ int jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device)
 void jur_model_destroy(jur_model_t *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
+  if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_lvl = m->d_crv = m->d_ue = NULL;
   void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_lvl, m->d_crv, m->d_ue, m->d_atm, m->d_order, m->d_sort_tmp,
                   m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
@@ -676,29 +678,92 @@ done:
     exit(EXIT_FAILURE);                                                          \
   } while (0)
 
+/* The reference serves concurrent callers (OpenMP threads) through up to 4 "lanes", each with its own
+ * stream and buffers (GPUdrivers.cu:262-342).  Same idea here: lane 0 is the process-lifetime model that
+ * owns the tables (like upstream's static tbl), further lanes are created on demand as shallow copies that
+ * share the table arrays and own their atmosphere, workspace and stream.  A small package (<= 1088 rays)
+ * leaves most of the GPU idle, so concurrent packages overlap almost perfectly. */
+#define JUR_MAX_LANES 16
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
-static jur_model_t *g_model = NULL;   /* process-lifetime cache, like upstream's static tbl */
+static pthread_cond_t g_cond = PTHREAD_COND_INITIALIZER;
+static jur_model_t *g_lane[JUR_MAX_LANES];   /* g_lane[0]: owner of the tables */
+static int g_busy[JUR_MAX_LANES];
+static int g_nlane = 0, g_maxlane = 0;
 
-static jur_model_t *global_model(ctl_t const *ctl) {
-  if (!g_model) {
+static jur_model_t *clone_lane(jur_model_t const *m) {
+  jur_model_t *c = (jur_model_t *)malloc(sizeof *c);
+  if (!c) return NULL;
+  *c = *m;
+  c->shared_tables = 1;
+  c->ctl = (ctl_t *)malloc(sizeof(ctl_t));
+  if (!c->ctl) { free(c); return NULL; }
+  memcpy(c->ctl, m->ctl, sizeof(ctl_t));
+  c->d_atm = NULL; c->atm_cap = 0; c->atm_slices = 0;
+  c->view.atm_np = 0;
+  c->d_los = NULL; c->d_eps = NULL; c->d_np = NULL; c->d_tsurf = NULL; c->d_status = NULL;
+  c->los_bytes = 0; c->ws_rays = 0; c->ws_trace_rays = 0;
+  c->d_order = NULL; c->d_sort_tmp = NULL; c->order_cap = 0; c->sort_tmp_bytes = 0;
+  c->d_io = NULL; c->d_io_np = NULL; c->io_cap = 0;
+  c->stream = NULL; c->timing = 0; c->evpool = NULL; c->evkind = NULL; c->ntimed = 0;
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void **)&c->d_status, sizeof(int)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
+    jur_model_destroy(c);
+    return NULL;
+  }
+  return c;
+}
+
+/* run-time switches of the control block are honoured on every call (upstream re-uploads ctl per call,
+ * GPUdrivers.cu:355); nu/emitter/tables are latched by the first call (jr_common.h:62-63) */
+static void refresh_switches(jur_model_t *m, ctl_t const *ctl) {
+  jur_view_t *v = &m->view;
+  if (ctl->ng != v->ng || ctl->nd != v->nd) DIE("ng/nd changed after the tables were initialised");
+  memcpy(m->ctl, ctl, sizeof(ctl_t));
+  v->refrac = ctl->refrac; v->write_bbt = ctl->write_bbt; v->rayds = ctl->rayds; v->raydz = ctl->raydz;
+  v->fourbit = ((1 == ctl->ctm_co2) && (v->ig_co2 >= 0)) * 8 + ((1 == ctl->ctm_h2o) && (v->ig_h2o >= 0)) * 4
+             + (1 == ctl->ctm_n2) * 2 + (1 == ctl->ctm_o2) * 1;
+}
+
+/* returns a lane index marked busy; blocks while all lanes are in use */
+static int acquire_lane(ctl_t const *ctl) {
+  pthread_mutex_lock(&g_lock);
+  if (g_nlane == 0) {   /* first call of the process: load the tables (upstream: get_tbl under omp critical) */
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
       DIE("no GPU found: this library has no CPU path (USEGPU = %d)", ctl->useGPU);
     int device = ctl->MPIlocalrank;               /* GPUdrivers.cu:344 */
     if (device < 0 || device >= ndev) device = 0;
     printf("Initialize emissivity tables and source function (MI355X path, device %d)...\n", device);
-    if (jur_model_create_from_files(&g_model, ctl, device) != JUR_OK) DIE("%s", jur_last_error());
-  } else {
-    /* upstream ignores later changes of nu/emitter but re-reads the rest of ctl on
-     * every call (GPUdrivers.cu:355); mirror the run-time switches */
-    jur_view_t *v = &g_model->view;
-    if (ctl->ng != v->ng || ctl->nd != v->nd) DIE("ng/nd changed after the tables were initialised");
-    memcpy(g_model->ctl, ctl, sizeof(ctl_t));
-    v->refrac = ctl->refrac; v->write_bbt = ctl->write_bbt; v->rayds = ctl->rayds; v->raydz = ctl->raydz;
-    v->fourbit = ((1 == ctl->ctm_co2) && (v->ig_co2 >= 0)) * 8 + ((1 == ctl->ctm_h2o) && (v->ig_h2o >= 0)) * 4
-               + (1 == ctl->ctm_n2) * 2 + (1 == ctl->ctm_o2) * 1;
+    if (jur_model_create_from_files(&g_lane[0], ctl, device) != JUR_OK) DIE("%s", jur_last_error());
+    g_nlane = 1;
+    char const *e = getenv("JUR_LANES");
+    g_maxlane = e ? atoi(e) : 4;
+    if (g_maxlane < 1) g_maxlane = 1;
+    if (g_maxlane > JUR_MAX_LANES) g_maxlane = JUR_MAX_LANES;
   }
-  return g_model;
+  int lane = -1;
+  for (;;) {
+    for (int i = 0; i < g_nlane && lane < 0; i++)
+      if (!g_busy[i]) lane = i;
+    if (lane < 0 && g_nlane < g_maxlane) {
+      g_lane[g_nlane] = clone_lane(g_lane[0]);
+      if (!g_lane[g_nlane]) DIE("cannot create another lane: %s", jur_last_error());
+      lane = g_nlane++;
+    }
+    if (lane >= 0) break;
+    pthread_cond_wait(&g_cond, &g_lock);
+  }
+  g_busy[lane] = 1;
+  pthread_mutex_unlock(&g_lock);
+  refresh_switches(g_lane[lane], ctl);
+  return lane;
+}
+
+static void release_lane(int lane) {
+  pthread_mutex_lock(&g_lock);
+  g_busy[lane] = 0;
+  pthread_cond_signal(&g_cond);
+  pthread_mutex_unlock(&g_lock);
 }
 
 static void formod_range(ctl_t const *ctl, atm_t *atm, obs_t *obs, int r0, int nr) {
@@ -706,11 +771,12 @@ static void formod_range(ctl_t const *ctl, atm_t *atm, obs_t *obs, int r0, int n
   if (!obs || !atm) DIE("null argument");
   if (r0 < 0 || nr < 0 || r0 + nr > JUR_NR) DIE("ray range outside the package (max %d rays)", JUR_NR);
   if (nr == 0) return;
-  pthread_mutex_lock(&g_lock);                    /* upstream: omp critical + lanes */
-  jur_model_t *m = global_model(ctl);
+  int const lane = acquire_lane(ctl);
+  jur_model_t *m = g_lane[lane];
   if (jur_model_set_atm(m, atm) != JUR_OK) DIE("%s", jur_last_error());
   int const nd = ctl->nd;
   double *buf = (double *)malloc(sizeof(double) * (size_t)nr * 2 * nd);
+  if (!buf) DIE("Out of memory!");
   double *rad = buf, *tau = buf + (size_t)nr * nd;
   for (int i = 0; i < nr; i++)
     for (int id = 0; id < nd; id++) rad[(size_t)i * nd + id] = obs->rad[r0 + i][id];
@@ -731,7 +797,7 @@ static void formod_range(ctl_t const *ctl, atm_t *atm, obs_t *obs, int r0, int n
     }
   }
   free(buf);
-  pthread_mutex_unlock(&g_lock);
+  release_lane(lane);
 }
 
 void formod_GPU(ctl_t const *ctl, atm_t *atm, obs_t *obs) { formod_range(ctl, atm, obs, 0, obs ? obs->nr : 0); }

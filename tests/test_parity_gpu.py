@@ -343,6 +343,57 @@ def test_model_from_files_uses_the_binary_cache(hip, oracle, tmp_path, monkeypat
         hip.Model(case.ctl)
 
 
+CONCURRENT = r"""
+import os, sys, time, threading
+sys.path[:0] = [{root!r}, os.path.join({root!r}, 'jurassic-gpu_amd'), os.path.join({root!r}, 'tests')]
+import numpy as np, common
+from jurassic_hip import abi, lib, synth
+case = common.limb_case(useGPU=1)
+case.write_files({tmp!r}, base='boxcar')
+def make_obs(seed):
+    g = synth.limb_geometry(1088, seed=seed)
+    o = abi.obs_t(); o.nr = len(g)
+    for k, name in enumerate(('time', 'obsz', 'obslon', 'obslat', 'vpz', 'vplon', 'vplat')):
+        np.ctypeslib.as_array(getattr(o, name))[:o.nr] = g[:, k]
+    return o
+nthr, ncall = 8, 4
+serial = []
+lib.formod(case.ctl, case.atm, make_obs(0))                    # loads the tables
+t0 = time.perf_counter()
+for t in range(nthr):
+    for c in range(ncall):
+        o = make_obs(100 * t + c); lib.formod(case.ctl, case.atm, o)
+        serial.append(np.ctypeslib.as_array(o.rad)[:1088, :2].copy())
+t_serial = time.perf_counter() - t0
+results = [None] * (nthr * ncall)
+def work(t):
+    for c in range(ncall):
+        o = make_obs(100 * t + c); lib.formod(case.ctl, case.atm, o)
+        results[t * ncall + c] = np.ctypeslib.as_array(o.rad)[:1088, :2].copy()
+threads = [threading.Thread(target=work, args=(t,)) for t in range(nthr)]
+t0 = time.perf_counter()
+for th in threads: th.start()
+for th in threads: th.join()
+t_conc = time.perf_counter() - t0
+assert all(np.array_equal(a, b) for a, b in zip(serial, results))
+print('CONCURRENT_OK serial %.3f s concurrent %.3f s speedup %.2f' % (t_serial, t_conc, t_serial / t_conc))
+"""
+
+
+def test_concurrent_drop_in_callers_use_lanes(hip, tmp_path):
+    """formod() is designed to be called from several threads at once (upstream: OpenMP callers and up
+    to 4 lanes, GPUdrivers.cu:262-342).  Eight threads, 1088-ray packages: bit-identical to the serial
+    results, and faster than serial because the packages overlap on the GPU."""
+    script = tmp_path / "concurrent.py"
+    script.write_text(CONCURRENT.format(root=common.ROOT, tmp=str(tmp_path)))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, JUR_LANES="8"))
+    assert out.returncode == 0 and "CONCURRENT_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    speedup = float(out.stdout.split("speedup")[1].split()[0])
+    print(out.stdout.strip().splitlines()[-1])
+    assert speedup > 1.2          # most of the wall time here is Python building obs_t under the GIL
+
+
 LIMB_CTL = """# Forward model...
 TBLBASE = ./boxcar
 NG = 5
