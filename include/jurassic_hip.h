@@ -115,6 +115,13 @@ size_t jur_state_size(jur_model_t const *m, atm_t const *atm);
 size_t jur_measurement_size(jur_model_t const *m, obs_t const *obs);
 int    jur_kernel(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t mrows, size_t ncols);
 
+/* Curtis-Godson means along each line of sight (reference curtis_godson(), jr_common.h:455-473, which
+ * upstream compiles only with -DCURTIS_GODSON for FORMOD=1): per ray, emitter and LOS point the
+ * column-weighted pressure cgp, temperature cgt and the cumulative column cgu.  Host arrays
+ * [nr][ng][JUR_NLOS]; entries from np[ray] on are 0.  tp (optional) and np_out (optional) as above. */
+int  jur_curtis_godson_host(jur_model_t *m, long nr, double const *const geom[7],
+                            double *cgp, double *cgt, double *cgu, double *const tp[3], int *np_out);
+
 /* Allocate the workspace for calls of up to nr rays now.  jur_formod_device allocates lazily on
  * first use; after jur_model_reserve (or one call of the same size) it only enqueues kernels on
  * the stream -- no allocation, no host synchronisation -- and can be captured into a HIP graph. */

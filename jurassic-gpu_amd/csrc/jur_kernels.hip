@@ -691,6 +691,54 @@ __global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chun
 }
 
 // ---------------------------------------------------------------------------------------
+// Curtis-Godson means along the path (curtis_godson, jr_common.h:455-473; upstream compiles it only
+// with -DCURTIS_GODSON for FORMOD=1 and never consumes the result): per gas, the inclusive prefix
+// sums over the LOS points of u p, u T and u, then cgp = S(u p)/S(u), cgt = S(u T)/S(u), cgu = S(u).
+// One wavefront per (ray, gas) pencil, lanes = LOS points: the along-path prefix is a wave scan
+// (shuffles), carried from one 64-point chunk to the next.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_inclusive_scan(double x, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    double const y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(256) void jur_cg_kernel(jur_view_t v, jur_chunk_t c, double *__restrict__ cgp,
+                                                     double *__restrict__ cgt, double *__restrict__ cgu) {
+  int const lane = threadIdx.x & 63;
+  long const wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // (slot, gas) pencil
+  int const ng = v.ng;
+  if (wave >= (long)c.n * ng) return;
+  int const r = (int)(wave / ng), g = (int)(wave - (long)r * ng);
+  long const ray = c.order ? (long)c.order[r] : c.first + r;
+  size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
+  double const *const lp = c.los + JUR_F_P * fs + r, *const lt = c.los + JUR_F_T * fs + r,
+               *const lu = c.los + (size_t)(JUR_F_K + v.nw + g) * fs + r;
+  int const np = c.np[r];
+  size_t const out = ((size_t)ray * ng + g) * NLOS;
+  double cp = 0, ct = 0, cu = 0;                                         // carry of the previous chunks
+  for (int base = 0; base < NLOS; base += 64) {
+    int const ip = base + lane;
+    double a = 0, b = 0, w = 0;
+    if (ip < np) {
+      double const u = lu[(size_t)ip * R];
+      a = u * lp[(size_t)ip * R];
+      b = u * lt[(size_t)ip * R];
+      w = u;
+    }
+    a = wave_inclusive_scan(a, lane) + cp;
+    b = wave_inclusive_scan(b, lane) + ct;
+    w = wave_inclusive_scan(w, lane) + cu;
+    cp = __shfl(a, 63, 64); ct = __shfl(b, 63, 64); cu = __shfl(w, 63, 64);
+    if (ip < np) { cgp[out + ip] = a / w; cgt[out + ip] = b / w; cgu[out + ip] = w; }
+    else if (ip < NLOS) { cgp[out + ip] = 0; cgt[out + ip] = 0; cgu[out + ip] = 0; }   // NLOS is not a multiple of 64
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // ray ordering key: altitude of the straight line's closest approach to the Earth's centre;
 // optionally grouped by the atmosphere slice the ray uses (neighbouring lanes then walk through
 // the same profile, i.e. the same table brackets)
@@ -761,6 +809,16 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
   int const nrb = (c->n + block - 1) / block;
   unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * v->nd);
   hipLaunchKernelGGL(jur_combine_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *v, *c, nrb);
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_launch_cg(jur_view_t const *v, jur_chunk_t const *c, double *cgp, double *cgt, double *cgu,
+                              void *stream) {
+  if (c->n <= 0 || v->ng <= 0) return 0;
+  int const block = 256;                                   // 4 pencils per workgroup
+  long const pencils = (long)c->n * v->ng;
+  unsigned const grid = (unsigned)((pencils * 64 + block - 1) / block);
+  hipLaunchKernelGGL(jur_cg_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *v, *c, cgp, cgt, cgu);
   return (int)hipGetLastError();
 }
 

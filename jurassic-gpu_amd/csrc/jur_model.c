@@ -550,6 +550,73 @@ int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double
   return JUR_OK;
 }
 
+/* ---- Curtis-Godson columns ------------------------------------------------------ */
+/* Traces the rays and returns, per ray, gas and LOS point, the Curtis-Godson pressure, temperature and
+ * cumulative column (curtis_godson, jr_common.h:455-473).  cgp/cgt/cgu are host arrays
+ * [nr][ng][JUR_NLOS] (points at and beyond np[ray] are 0); tp/np_out as in jur_formod_host. */
+int jur_curtis_godson_host(jur_model_t *m, long nr, double const *const geom[7], double *cgp, double *cgt, double *cgu,
+                           double *const tp[3], int *np_out) {
+  if (!m || nr < 1 || !cgp || !cgt || !cgu) { jur_set_error("curtis_godson: bad arguments"); return JUR_EINVAL; }
+  if (m->view.atm_np < 2) { jur_set_error("curtis_godson: no atmosphere set"); return JUR_EINVAL; }
+  HIPCHK(hipSetDevice(m->device));
+  int const ng = m->view.ng;
+  int rc = ensure_workspace(m, nr);
+  if (rc) return rc;
+  long const Rt = m->use_trace_rays;
+  hipStream_t s = m->stream;
+  size_t const per_ray = (size_t)(ng > 0 ? ng : 1) * JUR_NLOS;
+  double *d_geom = NULL, *d_out = NULL, *d_tp = NULL;
+  int *d_np = NULL;
+  hipError_t e = hipMalloc((void **)&d_geom, sizeof(double) * 7 * (size_t)nr);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_tp, sizeof(double) * 3 * (size_t)nr);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_np, sizeof(int) * (size_t)nr);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(double) * 3 * per_ray * (size_t)nr);
+  if (e != hipSuccess) { rc = JUR_EHIP; jur_set_error("curtis_godson: hipMalloc failed"); goto done; }
+  for (int k = 0; k < 7; k++)
+    if (hipMemcpyAsync(d_geom + (size_t)k * nr, geom[k], sizeof(double) * nr, hipMemcpyHostToDevice, s) != hipSuccess) { rc = JUR_EHIP; goto done; }
+  if (hipMemsetAsync(m->d_status, 0, sizeof(int), s) != hipSuccess) { rc = JUR_EHIP; goto done; }
+  {
+    double *d_cgp = d_out, *d_cgt = d_out + per_ray * (size_t)nr, *d_cgu = d_out + 2 * per_ray * (size_t)nr;
+    for (long t0 = 0; t0 < nr; t0 += Rt) {
+      jur_chunk_t c;
+      memset(&c, 0, sizeof c);
+      c.n = (int)((nr - t0 < Rt) ? nr - t0 : Rt);
+      c.stride = (int)Rt;
+      c.stride_eps = (int)m->use_rays;
+      c.first = t0;
+      c.order = NULL;
+      for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * nr;
+      for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * nr;
+      c.np_out = d_np;
+      c.np = m->d_np;
+      c.tsurf = m->d_tsurf;
+      c.los = m->d_los;
+      c.eps = m->d_eps;
+      c.status = m->d_status;
+      int ek = jurk_launch_trace(&m->view, &c, s);
+      if (!ek) ek = jurk_launch_cg(&m->view, &c, d_cgp, d_cgt, d_cgu, s);
+      if (ek) { jur_set_error("curtis_godson: kernel launch failed: %s", hipGetErrorString((hipError_t)ek)); rc = JUR_EHIP; goto done; }
+    }
+    int status = 0;
+    hipError_t ec = hipMemcpyAsync(cgp, d_cgp, sizeof(double) * per_ray * (size_t)nr, hipMemcpyDeviceToHost, s);
+    if (ec == hipSuccess) ec = hipMemcpyAsync(cgt, d_cgt, sizeof(double) * per_ray * (size_t)nr, hipMemcpyDeviceToHost, s);
+    if (ec == hipSuccess) ec = hipMemcpyAsync(cgu, d_cgu, sizeof(double) * per_ray * (size_t)nr, hipMemcpyDeviceToHost, s);
+    for (int k = 0; k < 3 && tp && ec == hipSuccess; k++)
+      ec = hipMemcpyAsync(tp[k], d_tp + (size_t)k * nr, sizeof(double) * nr, hipMemcpyDeviceToHost, s);
+    if (np_out && ec == hipSuccess) ec = hipMemcpyAsync(np_out, d_np, sizeof(int) * nr, hipMemcpyDeviceToHost, s);
+    if (ec == hipSuccess) ec = hipMemcpyAsync(&status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (ec == hipSuccess) ec = hipStreamSynchronize(s);
+    if (ec != hipSuccess) { jur_set_error("curtis_godson: copy back failed: %s", hipGetErrorString(ec)); rc = JUR_EHIP; goto done; }
+    if (status & 1) { jur_set_error("Too many LOS points! (a ray needs %d or more)", JUR_NLOS); rc = JUR_ENLOS; }
+  }
+done:
+  if (d_geom) (void)hipFree(d_geom);
+  if (d_tp) (void)hipFree(d_tp);
+  if (d_np) (void)hipFree(d_np);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
+}
+
 /* ---- retrieval Jacobian -------------------------------------------------------- */
 /* State vector of the atmosphere inside the retrieval windows (atm2x, jurassic.c:1491-1513):
  * quantity index iqa (0 p, 1 T, 2+g q, 2+ng+w k) and atmosphere point ipa per element. */

@@ -46,6 +46,7 @@ def lib():
         L.jur_model_destroy.argtypes = [C.c_void_p]
         L.jur_model_set_atm.argtypes = [C.c_void_p, C.c_void_p]
         L.jur_formod_host.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
+        L.jur_curtis_godson_host.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), dp, dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
         L.jur_formod_device.argtypes = [C.c_void_p, C.c_long] + [C.c_void_p] * 7
         L.jur_model_reserve.argtypes = [C.c_void_p, C.c_long]
         L.jur_model_workspace_bytes.restype = C.c_long
@@ -178,6 +179,17 @@ class Model:
         tarr = (dp * 3)(*[_p(tp[k]) for k in range(3)])
         _chk(lib().jur_formod_host(self.h, nr, garr, _p(rad), _p(tau), tarr, npts.ctypes.data_as(C.POINTER(C.c_int))))
         return dict(rad=rad, tau=tau, tp=np.ascontiguousarray(tp.T), np=npts)
+
+    def curtis_godson(self, geom):
+        """-> dict(cgp, cgt, cgu (nr, ng, NLOS), np)."""
+        g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
+        nr = g.shape[1]
+        out = [np.zeros((nr, max(self.ng, 1), abi.NLOS)) for _ in range(3)]
+        npts = np.zeros(nr, dtype=np.int32)
+        garr = (dp * 7)(*[_p(g[k]) for k in range(7)])
+        _chk(lib().jur_curtis_godson_host(self.h, nr, garr, _p(out[0]), _p(out[1]), _p(out[2]), None,
+                                          npts.ctypes.data_as(C.POINTER(C.c_int))))
+        return dict(cgp=out[0], cgt=out[1], cgu=out[2], np=npts)
 
     def formod_device(self, nr, d_geom, d_rad, d_tau, d_tp, d_np=0, d_status=0, stream=0):
         """All arguments are raw device addresses (ints), e.g. torch_tensor.data_ptr()."""

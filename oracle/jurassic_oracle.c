@@ -933,3 +933,32 @@ void orc_kernel(ctl_t const *ctl, atm_t *atm, obs_t *obs, orc_tbl_t const *tb, d
   }
   free(iqa); free(x0); free(x1); free(yy0); free(yy1); free(atm1); free(obs1);
 }
+
+/* ------------------------------------------------------------------------ */
+/* Curtis-Godson means, jr_common.h:455-473 (compiled upstream only with        */
+/* -DCURTIS_GODSON): sequential prefix sums per gas                             */
+/* ------------------------------------------------------------------------ */
+int orc_curtis_godson(ctl_t const *ctl, atm_t const *atm, double const geom[7], double *cgp, double *cgt, double *cgu) {
+  pos_t *los = (pos_t *)malloc(sizeof(pos_t) * NLOS);
+  double tsurf, tp[3];
+  int const np = traceray(ctl, atm, geom, los, &tsurf, tp);
+  for (int ig = 0; ig < ctl->ng; ig++) {
+    double *p = cgp + (size_t)ig * NLOS, *t = cgt + (size_t)ig * NLOS, *u = cgu + (size_t)ig * NLOS;
+    if (np > 0) {
+      p[0] = los[0].u[ig] * los[0].p;
+      t[0] = los[0].u[ig] * los[0].t;
+      u[0] = los[0].u[ig];
+    }
+    for (int ip = 1; ip < np; ip++) {
+      p[ip] = p[ip - 1] + los[ip].u[ig] * los[ip].p;
+      t[ip] = t[ip - 1] + los[ip].u[ig] * los[ip].t;
+      u[ip] = u[ip - 1] + los[ip].u[ig];
+    }
+    for (int ip = 0; ip < np; ip++) {
+      p[ip] /= u[ip];
+      t[ip] /= u[ip];
+    }
+  }
+  free(los);
+  return np;
+}

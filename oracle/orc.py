@@ -55,6 +55,8 @@ def lib():
         L.orc_traceray.restype = C.c_int
         L.orc_traceray.argtypes = [C.c_void_p, C.c_void_p] + [dp] * 12
         L.orc_hydrostatic.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_curtis_godson.restype = C.c_int
+        L.orc_curtis_godson.argtypes = [C.c_void_p, C.c_void_p, dp, dp, dp, dp]
         L.orc_atm2x.restype = C.c_size_t
         L.orc_atm2x.argtypes = [C.c_void_p, C.c_void_p, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_obs2y.restype = C.c_size_t
@@ -155,3 +157,10 @@ def kernel(ctl, atm, obs, tables):
     k = np.zeros((m, n))
     lib().orc_kernel(C.byref(ctl), C.byref(atm), C.byref(obs), tables.h, _p(k), m, n)
     return k
+
+
+def curtis_godson(ctl, atm, geom7):
+    g = np.ascontiguousarray(geom7, dtype=np.float64)
+    out = [np.zeros((max(ctl.ng, 1), abi.NLOS)) for _ in range(3)]
+    npts = lib().orc_curtis_godson(C.byref(ctl), C.byref(atm), _p(g), _p(out[0]), _p(out[1]), _p(out[2]))
+    return dict(cgp=out[0], cgt=out[1], cgu=out[2], np=npts)

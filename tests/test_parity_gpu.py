@@ -127,6 +127,29 @@ def test_table_shapes(hip, oracle, kw):
     assert_parity(out, ref)
 
 
+def test_curtis_godson_columns(hip, oracle):
+    """curtis_godson (jr_common.h:455-473): per gas the running column-weighted pressure and temperature
+    and the cumulative column along the path.  The device forms the along-path prefix sums with a
+    wavefront scan (different summation order than the sequential loop): 1e-12 relative."""
+    geom = np.vstack([synth.limb_geometry(150, seed=41, nprofiles=3), synth.nadir_geometry(30, seed=42, nprofiles=3)])
+    case = common.limb_case(geom=geom, nprofiles=3)
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    got = model.curtis_godson(case.geom)
+    for i in range(0, len(geom), 7):
+        ref = oracle.curtis_godson(case.ctl, case.atm, case.geom[i])
+        n = ref["np"]
+        assert got["np"][i] == n and n > 100
+        for key in ("cgp", "cgt", "cgu"):
+            a, b = got[key][i, :case.ctl.ng, :n], ref[key][:case.ctl.ng, :n]
+            # a gas that is absent at the top of the path has S(u) = 0 there: 0/0 in both implementations
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (i, key)
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=0, equal_nan=True)
+            assert np.all(got[key][i, :, n:] == 0)
+        assert np.all(np.diff(got["cgu"][i, 0, :n]) > 0)          # the column only grows
+    model.close()
+
+
 def test_heterogeneous_tables(hip, oracle):
     """Every (gas, channel) pair with its own pressure/temperature axes and grid ratio, and curves that
     degenerate to a single entry scattered through otherwise normal tables (the `nu < 2` early-out of
