@@ -54,6 +54,8 @@ typedef struct {
   int sorted_tables;            /* every axis and curve is non-decreasing: any bracket search
                                    finds what the reference's bisection finds                  */
   int atm_maxslice;             /* longest run of equal time stamps in the atmosphere          */
+  int max_pair_curves;          /* most curves any (gas, channel) pair has (LDS staging size)  */
+  int pad3;
   /* atmosphere, compact SoA of atm_np points */
   int atm_np;
   int atm_sorted;               /* time stamps non-decreasing and z strictly monotone inside every slice */
@@ -127,6 +129,7 @@ struct jur_tables {
 typedef struct {
   long nlevel, ncurve, nentry;
   int sorted;                   /* all axes and curves non-decreasing           */
+  int max_pair_curves;
   jur_int2 *pair;
   jur_lvl_t *lvl;
   jur_crv_t *crv;

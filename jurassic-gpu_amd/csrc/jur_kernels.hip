@@ -28,6 +28,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <cstdlib>
 #include "jur_internal.h"
 
 #define NLOS JUR_NLOS
@@ -447,33 +448,50 @@ __device__ __forceinline__ void seek_curve(void const *__restrict__ ue, unsigned
   }
 }
 
+// Table descriptors of ONE (gas, channel) pair as the look-up sees them: read from global memory, or
+// from a copy the workgroup has staged in LDS (every lane of the workgroup works on the same pair; LDS
+// reads are counted by lgkmcnt and stay out of the queue of the curve gathers).
+extern __shared__ __attribute__((aligned(16))) unsigned char jur_lds[];
+
+template <bool LDS>
+struct PairDesc {
+  void const *lvb, *cvb;       // global arrays
+  unsigned l0;                 // first level of the pair
+  unsigned kbase;              // first curve of the pair (LDS copy starts there)
+  __device__ __forceinline__ Lvl lvl(int i) const {
+    if constexpr (LDS) return reinterpret_cast<Lvl const *>(jur_lds)[i];
+    else return ldg<Lvl>(lvb, l0 + (unsigned)i);
+  }
+  __device__ __forceinline__ Crv crv(unsigned k) const {
+    if constexpr (LDS) return reinterpret_cast<Crv const *>(jur_lds + JUR_TBLNP * sizeof(Lvl))[k - kbase];
+    else return ldg<Crv>(cvb, k);
+  }
+};
+
 // per-gas search state carried from segment to segment (WARM only):
 //   br = ipr | it0 << 8 | it1 << 16,  ia = idx00 | idx01 << 16,  ib = idx10 | idx11 << 16
-template <bool WARM>
-__device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, double tau, double t, double u, double p,
-                                          unsigned &br, unsigned &ia, unsigned &ib) {
+template <bool WARM, bool LDS>
+__device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, PairDesc<LDS> const &D, double tau, double t,
+                                          double u, double p, unsigned &br, unsigned &ia, unsigned &ib) {
   if (tau < 1e-9) return 0.;
   jur_int2 const pr = v.pair[pair_idx];
   if (pr.a < 2) return 1.;
-  void const *const lvb = v.lvl;
-  void const *const cvb = v.crv;
   void const *const ueb = v.ue;
-  unsigned const l_0 = (unsigned)pr.b;
   int ipr;
   Lvl l0, l1;
   if (WARM) {
     ipr = min((int)(br & 0xffu), pr.a - 2);
-    l0 = ldg<Lvl>(lvb, l_0 + ipr); l1 = ldg<Lvl>(lvb, l_0 + ipr + 1);
-    while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = ldg<Lvl>(lvb, l_0 + ipr); }
-    while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = ldg<Lvl>(lvb, l_0 + ipr + 1); }
+    l0 = D.lvl(ipr); l1 = D.lvl(ipr + 1);
+    while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = D.lvl(ipr); }
+    while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = D.lvl(ipr + 1); }
   } else {  // locate_id, jr_common.h:106-114 (ascending-only bisection, whatever the axis looks like)
     int ilo = 0, ihi = pr.a - 1;
     while (ihi > ilo + 1) {
       int const i = (ihi + ilo) >> 1;
-      if (ldg<Lvl>(lvb, l_0 + i).p > p) ihi = i; else ilo = i;
+      if (D.lvl(i).p > p) ihi = i; else ilo = i;
     }
     ipr = ilo;
-    l0 = ldg<Lvl>(lvb, l_0 + ipr); l1 = ldg<Lvl>(lvb, l_0 + ipr + 1);
+    l0 = D.lvl(ipr); l1 = D.lvl(ipr + 1);
   }
   if (WARM) br = (br & ~0xffu) | (unsigned)ipr;
   if (l0.nt < 2 || l1.nt < 2) return 1.;
@@ -483,30 +501,30 @@ __device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, dou
   if (WARM) {
     it0 = min((int)((br >> 8) & 0xffu), l0.nt - 2);
     it1 = min((int)((br >> 16) & 0xffu), l1.nt - 2);
-    c00 = ldg<Crv>(cvb, k0 + it0); c01_ = ldg<Crv>(cvb, k0 + it0 + 1);
-    c10 = ldg<Crv>(cvb, k1 + it1); c11 = ldg<Crv>(cvb, k1 + it1 + 1);
-    while (t < c00.t && it0 > 0) { --it0; c01_ = c00; c00 = ldg<Crv>(cvb, k0 + it0); }
-    while (t >= c01_.t && it0 < l0.nt - 2) { ++it0; c00 = c01_; c01_ = ldg<Crv>(cvb, k0 + it0 + 1); }
-    while (t < c10.t && it1 > 0) { --it1; c11 = c10; c10 = ldg<Crv>(cvb, k1 + it1); }
-    while (t >= c11.t && it1 < l1.nt - 2) { ++it1; c10 = c11; c11 = ldg<Crv>(cvb, k1 + it1 + 1); }
+    c00 = D.crv(k0 + it0); c01_ = D.crv(k0 + it0 + 1);
+    c10 = D.crv(k1 + it1); c11 = D.crv(k1 + it1 + 1);
+    while (t < c00.t && it0 > 0) { --it0; c01_ = c00; c00 = D.crv(k0 + it0); }
+    while (t >= c01_.t && it0 < l0.nt - 2) { ++it0; c00 = c01_; c01_ = D.crv(k0 + it0 + 1); }
+    while (t < c10.t && it1 > 0) { --it1; c11 = c10; c10 = D.crv(k1 + it1); }
+    while (t >= c11.t && it1 < l1.nt - 2) { ++it1; c10 = c11; c11 = D.crv(k1 + it1 + 1); }
     br = (unsigned)ipr | ((unsigned)it0 << 8) | ((unsigned)it1 << 16);
     if (c00.nu < 2 || c01_.nu < 2 || c10.nu < 2 || c11.nu < 2) return 1.;
   } else {
     int ilo = 0, ihi = l0.nt - 1;
     while (ihi > ilo + 1) {
       int const i = (ihi + ilo) >> 1;
-      if (ldg<Crv>(cvb, k0 + i).t > t) ihi = i; else ilo = i;
+      if (D.crv(k0 + i).t > t) ihi = i; else ilo = i;
     }
     it0 = ilo;
-    c00 = ldg<Crv>(cvb, k0 + it0); c01_ = ldg<Crv>(cvb, k0 + it0 + 1);
+    c00 = D.crv(k0 + it0); c01_ = D.crv(k0 + it0 + 1);
     if (c00.nu < 2 || c01_.nu < 2) return 1.;
     ilo = 0; ihi = l1.nt - 1;
     while (ihi > ilo + 1) {
       int const i = (ihi + ilo) >> 1;
-      if (ldg<Crv>(cvb, k1 + i).t > t) ihi = i; else ilo = i;
+      if (D.crv(k1 + i).t > t) ihi = i; else ilo = i;
     }
     it1 = ilo;
-    c10 = ldg<Crv>(cvb, k1 + it1); c11 = ldg<Crv>(cvb, k1 + it1 + 1);
+    c10 = D.crv(k1 + it1); c11 = D.crv(k1 + it1 + 1);
     if (c10.nu < 2 || c11.nu < 2) return 1.;
   }
 
@@ -609,7 +627,7 @@ __device__ __forceinline__ double planck_src(double const *__restrict__ sr, doub
 // from that XCD's L2): b -> xcd = b % 8, s = b / 8, ray block = (s / npair) * 8 + xcd,
 // pair = s % npair.  Placement only affects speed.
 // ---------------------------------------------------------------------------------------
-template <bool WARM>
+template <bool WARM, bool LDS>
 __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
   int const npair = v.nd * v.ng;
   int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
@@ -617,9 +635,23 @@ __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t 
   if (rb >= nrb) return;
   int const d = pr / v.ng, g = pr - d * v.ng;
   int const r = rb * blockDim.x + threadIdx.x;
-  if (r >= c.n) return;
   int const pair_idx = g * v.nd + d;
-  if (v.pair[pair_idx].a < 2) return;            // no table: transmittance 1, the combine kernel knows
+  jur_int2 const pd = v.pair[pair_idx];
+  if (pd.a < 2) return;                          // no table: transmittance 1, the combine kernel knows
+  PairDesc<LDS> D{v.lvl, v.crv, (unsigned)pd.b, 0u};
+  if (LDS) {  // stage the pair's level and curve descriptors (16 B each) once per workgroup
+    Lvl const *const gl = reinterpret_cast<Lvl const *>(v.lvl) + pd.b;
+    Lvl const first = gl[0], last = gl[pd.a - 1];
+    D.kbase = (unsigned)first.c0;
+    int const ncrv = last.c0 + last.nt - first.c0;
+    Lvl *const sl = reinterpret_cast<Lvl *>(jur_lds);
+    Crv *const sc = reinterpret_cast<Crv *>(jur_lds + JUR_TBLNP * sizeof(Lvl));
+    Crv const *const gc = reinterpret_cast<Crv const *>(v.crv) + first.c0;
+    for (int i = threadIdx.x; i < pd.a; i += blockDim.x) sl[i] = gl[i];
+    for (int i = threadIdx.x; i < ncrv; i += blockDim.x) sc[i] = gc[i];
+    __syncthreads();
+  }
+  if (r >= c.n) return;
   size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
   size_t const Re = (size_t)c.stride_eps, fe = (size_t)NLOS * Re;
   // planes of the workspace are addressed as (uniform row pointer) + lane offset
@@ -632,7 +664,7 @@ __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t 
   for (int ip = 0; ip < np; ++ip) {
     size_t const o = (size_t)ip * R;
     double const p = ldg<double>(los_p + o, r), t = ldg<double>(los_t + o, r), u = ldg<double>(los_u + o, r);
-    double const eps = ega_eps<WARM>(v, pair_idx, tau_path, t, u, p, br, ia, ib);
+    double const eps = ega_eps<WARM, LDS>(v, pair_idx, D, tau_path, t, u, p, br, ia, ib);
     tau_path *= eps;
     *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)((unsigned)r * 8u)) = eps;
   }
@@ -648,6 +680,14 @@ __global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chun
   int const rb = (sq / nd) * 8 + xcd, d = sq - (sq / nd) * nd;   // ray block, channel: uniform
   if (rb >= nrb) return;
   int const r = rb * blockDim.x + threadIdx.x;
+  // the channel's source-function table (1201 doubles) is staged in LDS: its two reads per segment are
+  // gathers by temperature, everything else this kernel loads is a coalesced stream
+  double *const sr = reinterpret_cast<double *>(jur_lds);
+  {
+    double const *const gsr = v.sr + (size_t)d * TBLNS;
+    for (int i = threadIdx.x; i < TBLNS; i += blockDim.x) sr[i] = gsr[i];
+    __syncthreads();
+  }
   if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
   size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
@@ -655,7 +695,6 @@ __global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chun
   double const *const los = c.los;
   double const *const epsb = c.eps + (size_t)d * ng * fe;
   jur_chan_t const ch = v.chan[d];
-  double const *const sr = v.sr + (size_t)d * TBLNS;
   int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
   bool const do_co2 = (v.fourbit & 8) && ch.co2_on, do_h2o = (v.fourbit & 4) && ch.h2o_on,
              do_n2 = (v.fourbit & 2) && ch.n2_on, do_o2 = (v.fourbit & 1) && ch.o2_on;
@@ -798,8 +837,16 @@ extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *
   int const nrb = (c->n + block - 1) / block, npair = v->nd * v->ng;
   unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * npair);
   hipStream_t s = (hipStream_t)stream;
-  if (v->sorted_tables) hipLaunchKernelGGL(jur_ega_kernel<true>, dim3(grid), dim3(block), 0, s, *v, *c, nrb);
-  else hipLaunchKernelGGL(jur_ega_kernel<false>, dim3(grid), dim3(block), 0, s, *v, *c, nrb);
+  // LDS copy of one pair's descriptors per workgroup: 16 B x (levels + curves of the largest pair)
+  size_t const lds = sizeof(jur_lvl_t) * JUR_TBLNP + sizeof(jur_crv_t) * (size_t)v->max_pair_curves;
+  bool const use_lds = v->max_pair_curves > 0 && lds <= 32 * 1024 && !getenv("JUR_EGA_NO_LDS");
+  if (v->sorted_tables) {
+    if (use_lds) hipLaunchKernelGGL((jur_ega_kernel<true, true>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
+    else hipLaunchKernelGGL((jur_ega_kernel<true, false>), dim3(grid), dim3(block), 0, s, *v, *c, nrb);
+  } else {
+    if (use_lds) hipLaunchKernelGGL((jur_ega_kernel<false, true>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
+    else hipLaunchKernelGGL((jur_ega_kernel<false, false>), dim3(grid), dim3(block), 0, s, *v, *c, nrb);
+  }
   return (int)hipGetLastError();
 }
 
@@ -808,7 +855,8 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
   int const block = 256;
   int const nrb = (c->n + block - 1) / block;
   unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * v->nd);
-  hipLaunchKernelGGL(jur_combine_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *v, *c, nrb);
+  hipLaunchKernelGGL(jur_combine_kernel, dim3(grid), dim3(block), sizeof(double) * JUR_TBLNS, (hipStream_t)stream, *v, *c,
+                     nrb);
   return (int)hipGetLastError();
 }
 

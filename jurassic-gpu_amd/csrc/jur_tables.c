@@ -351,6 +351,12 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
     }
   }
   out->sorted = sorted;
+  out->max_pair_curves = 0;
+  for (long i = 0; i < npair; i++) {
+    int nc = 0;
+    for (int ip = 0; ip < tb->pair[i].np; ip++) nc += tb->pair[i].lv[ip].nt;
+    if (nc > out->max_pair_curves) out->max_pair_curves = nc;
+  }
   return JUR_OK;
 }
 
