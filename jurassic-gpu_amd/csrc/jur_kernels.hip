@@ -295,13 +295,25 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
         double xh[3], zz, llon, llat, pp, tt;
         for (int i = 0; i < 3; i++) xh[i] = x[i] + 0.5 * ds * ex0[i];
         cart2geo(xh, zz, llon, llat);
-        intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
+        int const ib = intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
         double const n2 = refractivity(pp, tt);
+        // the three displaced probes lie 0.02 km away: almost always in the bracket just found, whose six
+        // values are then reused instead of being looked up and loaded again
+        double const za = v.atm_z[ib], zb = v.atm_z[ib + 1], pa = v.atm_p[ib], pb = v.atm_p[ib + 1],
+                     ta = v.atm_t[ib], tb = v.atm_t[ib + 1], sl = v.atm_pslope[ib];
+        bool const first = (ib == atm0), lastb = (ib == atm0 + atmn - 2);
         for (int i = 0; i < 3; i++) {
           double const h = 0.02;
           xh[i] += h;
           cart2geo(xh, zz, llon, llat);
-          intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
+          bool const inside = (zdir > 0) ? ((zz >= za || first) && (zz < zb || lastb))
+                            : (zdir < 0) ? ((zz < za || first) && (zz >= zb || lastb)) : false;
+          if (inside) {
+            pp = (sl == sl) ? pa * exp(sl * (zz - za)) : lip(za, pa, zb, pb, zz);
+            tt = lip(za, ta, zb, tb, zz);
+          } else {
+            intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
+          }
           ngr[i] = (refractivity(pp, tt) - n2) / h;
           xh[i] -= h;
         }
