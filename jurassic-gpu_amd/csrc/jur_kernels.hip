@@ -222,6 +222,12 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
     int const zdir = (v.atm_sorted && atmn >= 2) ? ((v.atm_z[atm0] < v.atm_z[atm0 + 1]) ? 1 : -1) : 0;
     int zhint = (zdir > 0) ? atmn - 2 : 0, rhint = zhint;   // rays usually enter at the top
 
+    constexpr int QMAX = 6;
+    bool const fused = v.ng <= QMAX;                       // wave-uniform
+    double ds_p = 0, ds_pp = 0, p_p = 0, t_p = 0, q_p[QMAX];
+#pragma unroll
+    for (int ig = 0; ig < QMAX; ig++) q_p[ig] = 0;
+
     int stop = 0;
     for (; np < NLOS; ++np) {
       double ds = v.rayds;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
           for (int i = 0; i < 3; i++) x[i] = xh[i] + frac * (x[i] - xh[i]);
           z = norm3(x) - JUR_RE;
           double const dsp = ds * frac;
-          F(JUR_F_DS, np - 1) = dsp;
+          if (fused) ds_p = dsp; else F(JUR_F_DS, np - 1) = dsp;
           if (low_idx == np - 1) lds1 = dsp;
           if (low_idx + 1 == np - 1) lds2 = dsp;
         }
@@ -255,13 +261,33 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
 
       double p, t;
       int const ia = intpol_pt(v, atm0, atmn, z, p, t, zdir, zhint);
+      // With few gases the trapezoid rule and the column densities (jr_common.h:437-453) are applied one
+      // point late -- point np-1 is complete once point np has fixed its segment length -- instead of in a
+      // second sweep over the ray's column: its p, T and mixing ratios wait in registers.
+      if (fused && np > 0) {
+        double const dsn = (np >= 2) ? 0.5 * (ds_pp + ds_p) : ds_p * 0.5;   // ds_p already carries a clipping
+        F(JUR_F_DS, np - 1) = dsn;
+#pragma unroll
+        for (int ig = 0; ig < QMAX; ig++)
+          if (ig < v.ng) F(f_u + ig, np - 1) = 10. * q_p[ig] * p_p / (JUR_BOLTZMANN * t_p) * dsn;
+      }
       {  // remaining quantities on the same bracket (jr_common.h:557-567)
         double const za = v.atm_z[ia], zb = v.atm_z[ia + 1];
-        for (int ig = 0; ig < v.ng; ig++) {
-          double const *q = v.atm_q + (size_t)ig * v.atm_np;
-          double const qv = lip(za, q[ia], zb, q[ia + 1], z);
-          F(f_u + ig, np) = qv;  // mixing ratio now, column density after the trapezoid pass
-          if (ig == v.ig_h2o) F(JUR_F_QH2O, np) = qv;
+        if (fused) {
+#pragma unroll
+          for (int ig = 0; ig < QMAX; ig++)
+            if (ig < v.ng) {
+              double const *q = v.atm_q + (size_t)ig * v.atm_np;
+              q_p[ig] = lip(za, q[ia], zb, q[ia + 1], z);
+              if (ig == v.ig_h2o) F(JUR_F_QH2O, np) = q_p[ig];
+            }
+        } else {
+          for (int ig = 0; ig < v.ng; ig++) {
+            double const *q = v.atm_q + (size_t)ig * v.atm_np;
+            double const qv = lip(za, q[ia], zb, q[ia + 1], z);
+            F(f_u + ig, np) = qv;  // mixing ratio now, column density after the trapezoid pass
+            if (ig == v.ig_h2o) F(JUR_F_QH2O, np) = qv;
+          }
         }
         for (int iw = 0; iw < v.nw; iw++) {
           double const *k = v.atm_k + (size_t)iw * v.atm_np;
@@ -270,7 +296,8 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
       }
       F(JUR_F_P, np) = p;
       F(JUR_F_T, np) = t;
-      F(JUR_F_DS, np) = ds;
+      if (fused) { ds_pp = ds_p; ds_p = ds; p_p = p; t_p = t; }
+      else F(JUR_F_DS, np) = ds;
 
       if (low_idx >= 0 && low_idx == np - 1) { lz2 = z; lds2 = ds; for (int i = 0; i < 3; i++) lx2[i] = x[i]; }
       if (z < z_low) {
@@ -358,15 +385,25 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
       cart2geo(w, dummy, tplon, tplat);
     }
 
-    // trapezoid rule on ds (descending, jr_common.h:437-443), then column densities (:446-453)
-    for (int ip = np - 1; ip >= 0; ip--) {
-      double const dsr = F(JUR_F_DS, ip);
-      double const dsn = (ip >= 1) ? 0.5 * (F(JUR_F_DS, ip - 1) + dsr) : dsr * 0.5;
-      F(JUR_F_DS, ip) = dsn;
-      double const p = F(JUR_F_P, ip), t = F(JUR_F_T, ip);
-      for (int ig = 0; ig < v.ng; ig++) {
-        double const q = F(f_u + ig, ip);
-        F(f_u + ig, ip) = 10. * q * p / (JUR_BOLTZMANN * t) * dsn;
+    if (fused) {  // the last point
+      if (np > 0) {
+        double const dsn = (np >= 2) ? 0.5 * (ds_pp + ds_p) : ds_p * 0.5;
+        F(JUR_F_DS, np - 1) = dsn;
+#pragma unroll
+        for (int ig = 0; ig < QMAX; ig++)
+          if (ig < v.ng) F(f_u + ig, np - 1) = 10. * q_p[ig] * p_p / (JUR_BOLTZMANN * t_p) * dsn;
+      }
+    } else {
+      // trapezoid rule on ds (descending, jr_common.h:437-443), then column densities (:446-453)
+      for (int ip = np - 1; ip >= 0; ip--) {
+        double const dsr = F(JUR_F_DS, ip);
+        double const dsn = (ip >= 1) ? 0.5 * (F(JUR_F_DS, ip - 1) + dsr) : dsr * 0.5;
+        F(JUR_F_DS, ip) = dsn;
+        double const p = F(JUR_F_P, ip), t = F(JUR_F_T, ip);
+        for (int ig = 0; ig < v.ng; ig++) {
+          double const q = F(f_u + ig, ip);
+          F(f_u + ig, ip) = 10. * q * p / (JUR_BOLTZMANN * t) * dsn;
+        }
       }
     }
   }
