@@ -458,7 +458,9 @@ __device__ __forceinline__ int bisect_curve(void const *__restrict__ ue, unsigne
 // gallop, then bisect inside the gap.
 template <bool ON_EPS>
 __device__ __forceinline__ void seek_curve(void const *__restrict__ ue, unsigned e0, int n, double x, int &i, Ue &a, Ue &b) {
-  if (x >= ukey<ON_EPS>(b)) {
+  bool const up = x >= ukey<ON_EPS>(b), down = x < ukey<ON_EPS>(a);
+  if (!(up | down)) return;                      // one test for the common case: still in the bracket
+  if (up) {
     if (i >= n - 2) return;
     Ue const c = ld_ue(ue, e0 + i + 2);
     if (i + 2 >= n - 1 || ukey<ON_EPS>(c) > x) { ++i; a = b; b = c; return; }
@@ -476,7 +478,7 @@ __device__ __forceinline__ void seek_curve(void const *__restrict__ ue, unsigned
     }
     i = lo;
     ld_pair(ue, e0 + i, a, b);
-  } else if (x < ukey<ON_EPS>(a)) {
+  } else {
     if (i <= 0) return;
     Ue const c = ld_ue(ue, e0 + i - 1);
     if (i - 1 <= 0 || ukey<ON_EPS>(c) <= x) { --i; b = a; a = c; return; }
@@ -531,8 +533,10 @@ __device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, Pai
   if (WARM) {
     ipr = min((int)(br & 0xffu), pr.a - 2);
     l0 = D.lvl(ipr); l1 = D.lvl(ipr + 1);
-    while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = D.lvl(ipr); }
-    while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = D.lvl(ipr + 1); }
+    if ((p < l0.p) | (p >= l1.p)) {
+      while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = D.lvl(ipr); }
+      while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = D.lvl(ipr + 1); }
+    }
   } else {  // locate_id, jr_common.h:106-114 (ascending-only bisection, whatever the axis looks like)
     int ilo = 0, ihi = pr.a - 1;
     while (ihi > ilo + 1) {
@@ -552,10 +556,12 @@ __device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, Pai
     it1 = min((int)((br >> 16) & 0xffu), l1.nt - 2);
     c00 = D.crv(k0 + it0); c01_ = D.crv(k0 + it0 + 1);
     c10 = D.crv(k1 + it1); c11 = D.crv(k1 + it1 + 1);
-    while (t < c00.t && it0 > 0) { --it0; c01_ = c00; c00 = D.crv(k0 + it0); }
-    while (t >= c01_.t && it0 < l0.nt - 2) { ++it0; c00 = c01_; c01_ = D.crv(k0 + it0 + 1); }
-    while (t < c10.t && it1 > 0) { --it1; c11 = c10; c10 = D.crv(k1 + it1); }
-    while (t >= c11.t && it1 < l1.nt - 2) { ++it1; c10 = c11; c11 = D.crv(k1 + it1 + 1); }
+    if ((t < c00.t) | (t >= c01_.t) | (t < c10.t) | (t >= c11.t)) {
+      while (t < c00.t && it0 > 0) { --it0; c01_ = c00; c00 = D.crv(k0 + it0); }
+      while (t >= c01_.t && it0 < l0.nt - 2) { ++it0; c00 = c01_; c01_ = D.crv(k0 + it0 + 1); }
+      while (t < c10.t && it1 > 0) { --it1; c11 = c10; c10 = D.crv(k1 + it1); }
+      while (t >= c11.t && it1 < l1.nt - 2) { ++it1; c10 = c11; c11 = D.crv(k1 + it1 + 1); }
+    }
     br = (unsigned)ipr | ((unsigned)it0 << 8) | ((unsigned)it1 << 16);
     if (c00.nu < 2 || c01_.nu < 2 || c10.nu < 2 || c11.nu < 2) return 1.;
   } else {
