@@ -762,6 +762,8 @@ __global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chun
   bool const masked = !isfinite(c.rad[oidx]);
   double rad = 0.0, tau = 1.0;
   int const np = c.np[r];
+  unsigned has_table = 0;                              // gases with a table for this channel (uniform)
+  for (int g = 0; g < ng && g < 32; g++) has_table |= (v.pair[g * nd + d].a >= 2 ? 1u : 0u) << g;
   for (int ip = 0; ip < np; ++ip) {
     size_t const o = (size_t)ip * R;
     auto L = [&](int field) { return ldg<double>(los + (size_t)field * fs + o, r); };
@@ -773,7 +775,7 @@ __global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chun
     if (do_o2) beta_ds += ctm_o2(ch, p, t) * ds;
     double tau_gas = 1.0;
     for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
-      if (v.pair[g * nd + d].a >= 2) tau_gas *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
+      if ((has_table >> g) & 1u) tau_gas *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
     double const src = planck_src(sr, t);
     if (tau_gas > 1e-50) {  // jr_common.h:293-300
       double const eps = 1. - tau_gas * exp(-beta_ds);
