@@ -112,6 +112,54 @@ def test_formod_executable_parses_control_file_and_overrides(tmp_path):
     assert bad.returncode != 0 and "Missing variable EMITTER[1]" in bad.stdout
 
 
+LIMB_CTL = "TBLBASE = ./boxcar\nNG = 5\nEMITTER[0] = CO2\nEMITTER[1] = H2O\nEMITTER[2] = O3\nEMITTER[3] = F11\n" \
+           "EMITTER[4] = CCl4\nND = 2\nNU[0] = 792.0000\nNU[1] = 832.0000\n"
+NADIR_CTL = "TBLBASE = ./airs\nNG = 1\nEMITTER[0] = CO2\nND = 3\nNU[0] = 667.7820\nNU[1] = 668.5410\n" \
+            "NU[2] = 669.8110\nWRITE_BBT = 1\n"
+
+
+@pytest.mark.parametrize("name,ctl,obs_tool,obs_args", [
+    ("limb", LIMB_CTL, "limb", ["Z0", "3", "Z1", "68", "DZ", "1.0"]),        # example/limb/run.sh:8-11
+    ("nadir", NADIR_CTL, "nadir", ["T1", "10"]),                              # example/nadir/run.sh:8-11
+])
+def test_generators_reproduce_the_shipped_example_inputs(tmp_path, name, ctl, obs_tool, obs_args):
+    """`climatology` and `limb`/`nadir` called as the reference's run.sh calls them write files that are
+    byte-identical to the atm.tab / obs.tab the reference ships (tests/golden): pins the climatology
+    numbers, the profile interpolation, the scan geometry and the %g text format."""
+    import subprocess
+    bindir = os.path.join(ROOT, "jurassic-gpu_amd")
+    (tmp_path / "x.ctl").write_text(ctl)
+    for exe, target, extra in (("climatology", "atm.tab", []), (obs_tool, "obs.tab", obs_args)):
+        out = subprocess.run([os.path.join(bindir, exe), "x.ctl", target] + extra, cwd=tmp_path,
+                             capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stdout + out.stderr
+        got = (tmp_path / target).read_bytes()
+        want = open(os.path.join(common.GOLD, name, target), "rb").read()
+        assert got == want, f"{exe}: {target} differs from the shipped file"
+
+
+def test_climatology_random_profiles_and_checkmode(tmp_path):
+    """RAND=1 perturbs each profile by one (dp, dT) pair within +-5 % / +-30 K (climatology.c:65-78);
+    CHECKMODE writes nothing."""
+    import subprocess
+    exe = os.path.join(ROOT, "jurassic-gpu_amd", "climatology")
+    (tmp_path / "x.ctl").write_text(LIMB_CTL)
+    run = lambda *a: subprocess.run([exe, "x.ctl", *a], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert run("base.tab", "T1", "3").returncode == 0
+    assert run("rand.tab", "T1", "3", "RAND", "1").returncode == 0
+    from jurassic_hip import textio
+    ctl = abi.make_ctl(["CO2", "H2O", "O3", "F11", "CCl4"], [792.0, 832.0])
+    a, b = textio.read_atm(str(tmp_path / "base.tab"), ctl), textio.read_atm(str(tmp_path / "rand.tab"), ctl)
+    assert a.np == b.np == 4 * 91
+    pa, pb = np.ctypeslib.as_array(a.p)[:a.np], np.ctypeslib.as_array(b.p)[:a.np]
+    ta, tb = np.ctypeslib.as_array(a.t)[:a.np], np.ctypeslib.as_array(b.t)[:a.np]
+    dp, dt = (pb / pa - 1).reshape(4, 91), (tb - ta).reshape(4, 91)
+    assert np.all(np.abs(dp) <= 0.05 + 1e-5) and np.all(np.abs(dt) <= 30 + 1e-3)
+    assert np.all(np.ptp(dp, axis=1) < 2e-5) and np.all(np.ptp(dt, axis=1) < 2e-3)     # one draw per profile (%g text)
+    assert len(set(np.round(dt[:, 0], 3))) == 4                                             # profiles differ
+    assert run("none.tab", "CHECKMODE", "1").returncode == 0 and not (tmp_path / "none.tab").exists()
+
+
 def test_compute_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
