@@ -55,7 +55,8 @@ typedef struct {
                                    finds what the reference's bisection finds                  */
   int atm_maxslice;             /* longest run of equal time stamps in the atmosphere          */
   int max_pair_curves;          /* most curves any (gas, channel) pair has (LDS staging size)  */
-  int pad3;
+  int strict_axes;              /* sorted, and the p and T axes strictly increasing: the blends may divide by
+                                   multiplying with reciprocal bracket widths                                   */
   /* atmosphere, compact SoA of atm_np points */
   int atm_np;
   int atm_sorted;               /* time stamps non-decreasing and z strictly monotone inside every slice */
@@ -129,6 +130,7 @@ struct jur_tables {
 typedef struct {
   long nlevel, ncurve, nentry;
   int sorted;                   /* all axes and curves non-decreasing           */
+  int strict_axes;              /* ... and p, T axes strictly increasing        */
   int max_pair_curves;
   jur_int2 *pair;
   jur_lvl_t *lvl;

@@ -45,6 +45,18 @@ __device__ __forceinline__ double lip(double x0, double y0, double x1, double y1
   return y0 + (x - x0) * (y1 - y0) / (x1 - x0);
 }
 
+// The same interpolation with the bracket width's reciprocal r = RN(1/(x1 - x0)) at hand.  The quotient
+// a/b is formed as q = RN(a r), q' = RN(q + (a - b q) r) with fused multiply-adds: q' is the correctly
+// rounded a/b (Markstein 1990: r correctly rounded and q faithful suffice), i.e. the very double the
+// division returns, for 3 instructions instead of the ~14 of an fp64 division.  Needs b != 0 and finite.
+__device__ __forceinline__ double div_rcp(double a, double b, double r) {
+  double const q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double lip_rcp(double x0, double y0, double x1, double y1, double x, double r) {
+  return y0 + div_rcp((x - x0) * (y1 - y0), x1 - x0, r);
+}
+
 __device__ __forceinline__ double eip(double x0, double y0, double x1, double y1, double x) {
   if ((y0 > 0) && (y1 > 0)) return y0 * exp(log(y1 / y0) / (x1 - x0) * (x - x0));
   return lip(x0, y0, x1, y1, x);
@@ -478,6 +490,7 @@ __device__ __forceinline__ void seek_curve(void const *__restrict__ ue, unsigned
     }
     i = lo;
     ld_pair(ue, e0 + i, a, b);
+   
   } else {
     if (i <= 0) return;
     Ue const c = ld_ue(ue, e0 + i - 1);
@@ -496,6 +509,7 @@ __device__ __forceinline__ void seek_curve(void const *__restrict__ ue, unsigned
     }
     i = lo;
     ld_pair(ue, e0 + i, a, b);
+   
   }
 }
 
@@ -517,45 +531,94 @@ struct PairDesc {
     if constexpr (LDS) return reinterpret_cast<Crv const *>(jur_lds + JUR_TBLNP * sizeof(Lvl))[k - kbase];
     else return ldg<Crv>(cvb, k);
   }
+  // LDS only: 1/(p[i+1] - p[i]) and 1/(T[k+1] - T[k]), formed by the staging loop
+  unsigned rp_off, rt_off;     // byte offsets of the two reciprocal arrays in the LDS block
+  __device__ __forceinline__ double rp(int i) const { return reinterpret_cast<double const *>(jur_lds + rp_off)[i]; }
+  __device__ __forceinline__ double rt(unsigned k) const { return reinterpret_cast<double const *>(jur_lds + rt_off)[k - kbase]; }
 };
 
-// per-gas search state carried from segment to segment (WARM only):
-//   br = ipr | it0 << 8 | it1 << 16,  ia = idx00 | idx01 << 16,  ib = idx10 | idx11 << 16
-template <bool WARM, bool LDS>
-__device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, PairDesc<LDS> const &D, double tau, double t,
-                                          double u, double p, unsigned &br, unsigned &ia, unsigned &ib) {
+// EXACT look-up: the reference's bisections probe for probe (locate_id jr_common.h:106-114, locate_tbl_id
+// :116-125), for tables whose axes or curves are not sorted.
+template <bool LDS>
+__device__ __forceinline__ double ega_eps_exact(jur_view_t const &v, int pair_idx, PairDesc<LDS> const &D, double tau, double t,
+                                                double u, double p) {
   if (tau < 1e-9) return 0.;
   jur_int2 const pr = v.pair[pair_idx];
   if (pr.a < 2) return 1.;
   void const *const ueb = v.ue;
-  int ipr;
-  Lvl l0, l1;
-  if (WARM) {
-    ipr = min((int)(br & 0xffu), pr.a - 2);
-    l0 = D.lvl(ipr); l1 = D.lvl(ipr + 1);
-    if ((p < l0.p) | (p >= l1.p)) {
-      while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = D.lvl(ipr); }
-      while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = D.lvl(ipr + 1); }
-    }
-  } else {  // locate_id, jr_common.h:106-114 (ascending-only bisection, whatever the axis looks like)
-    int ilo = 0, ihi = pr.a - 1;
-    while (ihi > ilo + 1) {
-      int const i = (ihi + ilo) >> 1;
-      if (D.lvl(i).p > p) ihi = i; else ilo = i;
-    }
-    ipr = ilo;
-    l0 = D.lvl(ipr); l1 = D.lvl(ipr + 1);
+  int ilo = 0, ihi = pr.a - 1;
+  while (ihi > ilo + 1) {  // ascending-only bisection, whatever the axis looks like
+    int const i = (ihi + ilo) >> 1;
+    if (D.lvl(i).p > p) ihi = i; else ilo = i;
   }
-  if (WARM) br = (br & ~0xffu) | (unsigned)ipr;
+  Lvl const l0 = D.lvl(ilo), l1 = D.lvl(ilo + 1);
   if (l0.nt < 2 || l1.nt < 2) return 1.;
   unsigned const k0 = (unsigned)l0.c0, k1 = (unsigned)l1.c0;
-  int it0, it1;
-  Crv c00, c01_, c10, c11;
-  if (WARM) {
-    it0 = min((int)((br >> 8) & 0xffu), l0.nt - 2);
-    it1 = min((int)((br >> 16) & 0xffu), l1.nt - 2);
-    c00 = D.crv(k0 + it0); c01_ = D.crv(k0 + it0 + 1);
-    c10 = D.crv(k1 + it1); c11 = D.crv(k1 + it1 + 1);
+  ilo = 0; ihi = l0.nt - 1;
+  while (ihi > ilo + 1) {
+    int const i = (ihi + ilo) >> 1;
+    if (D.crv(k0 + i).t > t) ihi = i; else ilo = i;
+  }
+  Crv const c00 = D.crv(k0 + ilo), c01_ = D.crv(k0 + ilo + 1);
+  if (c00.nu < 2 || c01_.nu < 2) return 1.;
+  ilo = 0; ihi = l1.nt - 1;
+  while (ihi > ilo + 1) {
+    int const i = (ihi + ilo) >> 1;
+    if (D.crv(k1 + i).t > t) ihi = i; else ilo = i;
+  }
+  Crv const c10 = D.crv(k1 + ilo), c11 = D.crv(k1 + ilo + 1);
+  if (c10.nu < 2 || c11.nu < 2) return 1.;
+  // the four (p,T) corners: u at which the curve reaches eps (get_u, jr_common.h:179-185), then the
+  // curve's emissivity at that u plus the segment's column (get_eps, :156-177)
+  double const eps = 1 - tau;
+  unsigned const e0[4] = {(unsigned)c00.e0, (unsigned)c01_.e0, (unsigned)c10.e0, (unsigned)c11.e0};
+  int const n[4] = {c00.nu, c01_.nu, c10.nu, c11.nu};
+  double ec[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    Ue a, b;
+    ld_pair(ueb, e0[k] + bisect_curve<true>(ueb, e0[k], n[k], eps), a, b);
+    double const x = lip((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps) + u;
+    ld_pair(ueb, e0[k] + bisect_curve<false>(ueb, e0[k], n[k], x), a, b);
+    ec[k] = c01(lip((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, x));
+  }
+  double const eps_p0 = c01(lip(c00.t, ec[0], c01_.t, ec[1], t));
+  double const eps_p1 = c01(lip(c10.t, ec[2], c11.t, ec[3], t));
+  double const eps_t = c01(lip(l0.p, eps_p0, l1.p, eps_p1, p));
+  return (1. - eps_t) / tau;
+}
+
+// WARM look-up (sorted tables: every bracket is unique, so any search finds the reference's bracket).
+// Search state carried from segment to segment in three packed registers:
+//   br = ipr | it0 << 8 | it1 << 16,  ia = idx00 | idx01 << 16,  ib = idx10 | idx11 << 16
+// The curve positions kept are those where get_eps ended: the next segment's path emissivity is this
+// segment's result, i.e. close to eps(x) on every curve, so its get_u search usually starts inside its
+// bracket (-10 % kernel time against resuming from get_u's position).
+// The two pressure levels are handled one after the other by a rolled loop, two curves (the temperature
+// bracket of the level) at a time: half the curve state is live, 72 VGPRs, 7 waves per SIMD (-5 %
+// against all four curves side by side at 88 VGPRs).
+// RCPB (LDS copy present, p and T axes strictly increasing): the three blends divide by multiplying with
+// the reciprocal bracket widths staged in LDS (div_rcp) -- 3 of the look-up's 12 fp64 divisions.
+template <bool LDS, bool RCPB>
+__device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, int pair_idx, PairDesc<LDS> const &D, double tau, double t,
+                                               double u, double p, unsigned &br, unsigned &ia, unsigned &ib) {
+  static_assert(LDS || !RCPB, "the reciprocal widths live in LDS");
+  if (tau < 1e-9) return 0.;
+  jur_int2 const pr = v.pair[pair_idx];
+  if (pr.a < 2) return 1.;
+  void const *const ueb = v.ue;
+  int ipr = min((int)(br & 0xffu), pr.a - 2);
+  Lvl l0 = D.lvl(ipr), l1 = D.lvl(ipr + 1);
+  if ((p < l0.p) | (p >= l1.p)) {
+    while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = D.lvl(ipr); }
+    while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = D.lvl(ipr + 1); }
+  }
+  br = (br & ~0xffu) | (unsigned)ipr;
+  if (l0.nt < 2 || l1.nt < 2) return 1.;
+  unsigned const k0 = (unsigned)l0.c0, k1 = (unsigned)l1.c0;
+  int it0 = min((int)((br >> 8) & 0xffu), l0.nt - 2), it1 = min((int)((br >> 16) & 0xffu), l1.nt - 2);
+  {
+    Crv c00 = D.crv(k0 + it0), c01_ = D.crv(k0 + it0 + 1), c10 = D.crv(k1 + it1), c11 = D.crv(k1 + it1 + 1);
     if ((t < c00.t) | (t >= c01_.t) | (t < c10.t) | (t >= c11.t)) {
       while (t < c00.t && it0 > 0) { --it0; c01_ = c00; c00 = D.crv(k0 + it0); }
       while (t >= c01_.t && it0 < l0.nt - 2) { ++it0; c00 = c01_; c01_ = D.crv(k0 + it0 + 1); }
@@ -564,68 +627,45 @@ __device__ __forceinline__ double ega_eps(jur_view_t const &v, int pair_idx, Pai
     }
     br = (unsigned)ipr | ((unsigned)it0 << 8) | ((unsigned)it1 << 16);
     if (c00.nu < 2 || c01_.nu < 2 || c10.nu < 2 || c11.nu < 2) return 1.;
-  } else {
-    int ilo = 0, ihi = l0.nt - 1;
-    while (ihi > ilo + 1) {
-      int const i = (ihi + ilo) >> 1;
-      if (D.crv(k0 + i).t > t) ihi = i; else ilo = i;
-    }
-    it0 = ilo;
-    c00 = D.crv(k0 + it0); c01_ = D.crv(k0 + it0 + 1);
-    if (c00.nu < 2 || c01_.nu < 2) return 1.;
-    ilo = 0; ihi = l1.nt - 1;
-    while (ihi > ilo + 1) {
-      int const i = (ihi + ilo) >> 1;
-      if (D.crv(k1 + i).t > t) ihi = i; else ilo = i;
-    }
-    it1 = ilo;
-    c10 = D.crv(k1 + it1); c11 = D.crv(k1 + it1 + 1);
-    if (c10.nu < 2 || c11.nu < 2) return 1.;
   }
-
-  // the four (p,T) corners: u at which the curve reaches eps (get_u, jr_common.h:179-185), then the
-  // curve's emissivity at that u plus the segment's column (get_eps, :156-177).  The four curve
-  // loads of a stage are issued together.
   double const eps = 1 - tau;
-  unsigned const e0[4] = {(unsigned)c00.e0, (unsigned)c01_.e0, (unsigned)c10.e0, (unsigned)c11.e0};
-  int const n[4] = {c00.nu, c01_.nu, c10.nu, c11.nu};
-  int i[4];
-  Ue a[4], b[4];
-  if (WARM) {
-    i[0] = (int)(ia & 0xffffu); i[1] = (int)(ia >> 16); i[2] = (int)(ib & 0xffffu); i[3] = (int)(ib >> 16);
+  double eps_p0 = 0, eps_p1 = 0;
+#pragma unroll 1
+  for (int h = 0; h < 2; h++) {  // pressure level l0, then l1
+    unsigned const kc = h ? k1 + (unsigned)it1 : k0 + (unsigned)it0;
+    Crv const ca = D.crv(kc), cb = D.crv(kc + 1);
+    unsigned const packed = h ? ib : ia;
+    unsigned const e0[2] = {(unsigned)ca.e0, (unsigned)cb.e0};
+    int const n[2] = {ca.nu, cb.nu};
+    int i[2] = {(int)(packed & 0xffffu), (int)(packed >> 16)};
+    Ue a[2], b[2];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 2; k++) {
       i[k] = min(i[k], n[k] - 2);
       ld_pair(ueb, e0[k] + i[k], a[k], b[k]);
     }
+    // get_u (jr_common.h:179-185): u at which the curve reaches eps; get_eps (:156-177): the curve's
+    // emissivity at that u plus the segment's column -- the column only grows, so the second search
+    // starts where the first ended
+    double x[2], ec[2];
 #pragma unroll
-    for (int k = 0; k < 4; k++) seek_curve<true>(ueb, e0[k], n[k], eps, i[k], a[k], b[k]);
-    ia = (unsigned)i[0] | ((unsigned)i[1] << 16);
-    ib = (unsigned)i[2] | ((unsigned)i[3] << 16);
-  } else {
+    for (int k = 0; k < 2; k++) seek_curve<true>(ueb, e0[k], n[k], eps, i[k], a[k], b[k]);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      i[k] = bisect_curve<true>(ueb, e0[k], n[k], eps);
-      ld_pair(ueb, e0[k] + i[k], a[k], b[k]);
-    }
+    for (int k = 0; k < 2; k++) x[k] = lip((double)a[k].eps, (double)a[k].u, (double)b[k].eps, (double)b[k].u, eps) + u;
+#pragma unroll
+    for (int k = 0; k < 2; k++) seek_curve<false>(ueb, e0[k], n[k], x[k], i[k], a[k], b[k]);
+#pragma unroll
+    for (int k = 0; k < 2; k++) ec[k] = c01(lip((double)a[k].u, (double)a[k].eps, (double)b[k].u, (double)b[k].eps, x[k]));
+    unsigned const last = (unsigned)i[0] | ((unsigned)i[1] << 16);
+    if (h) ib = last; else ia = last;
+    double e;
+    if constexpr (RCPB) e = c01(lip_rcp(ca.t, ec[0], cb.t, ec[1], t, D.rt(kc)));
+    else e = c01(lip(ca.t, ec[0], cb.t, ec[1], t));
+    if (h) eps_p1 = e; else eps_p0 = e;
   }
-  double x[4], ec[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    x[k] = lip((double)a[k].eps, (double)a[k].u, (double)b[k].eps, (double)b[k].u, eps) + u;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (WARM) {
-      seek_curve<false>(ueb, e0[k], n[k], x[k], i[k], a[k], b[k]);   // the column only grows: start where get_u ended
-    } else {
-      i[k] = bisect_curve<false>(ueb, e0[k], n[k], x[k]);
-      ld_pair(ueb, e0[k] + i[k], a[k], b[k]);
-    }
-    ec[k] = c01(lip((double)a[k].u, (double)a[k].eps, (double)b[k].u, (double)b[k].eps, x[k]));
-  }
-  double const eps_p0 = c01(lip(c00.t, ec[0], c01_.t, ec[1], t));
-  double const eps_p1 = c01(lip(c10.t, ec[2], c11.t, ec[3], t));
-  double const eps_t = c01(lip(l0.p, eps_p0, l1.p, eps_p1, p));
+  double eps_t;
+  if constexpr (RCPB) eps_t = c01(lip_rcp(l0.p, eps_p0, l1.p, eps_p1, p, D.rp(ipr)));
+  else eps_t = c01(lip(l0.p, eps_p0, l1.p, eps_p1, p));
   return (1. - eps_t) / tau;
 }
 
@@ -682,8 +722,9 @@ __device__ __forceinline__ double planck_src(double const *__restrict__ sr, doub
 // from that XCD's L2): b -> xcd = b % 8, s = b / 8, ray block = (s / npair) * 8 + xcd,
 // pair = s % npair.  Placement only affects speed.
 // ---------------------------------------------------------------------------------------
-template <bool WARM, bool LDS>
-__global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
+template <bool WARM, bool LDS, bool RCPB>
+__global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
+  static_assert(WARM || !RCPB, "reciprocal widths need strictly increasing axes");
   int const npair = v.nd * v.ng;
   int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
   int const rb = (sq / npair) * 8 + xcd, pr = sq - (sq / npair) * npair;   // ray block, pair: uniform
@@ -693,7 +734,7 @@ __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t 
   int const pair_idx = g * v.nd + d;
   jur_int2 const pd = v.pair[pair_idx];
   if (pd.a < 2) return;                          // no table: transmittance 1, the combine kernel knows
-  PairDesc<LDS> D{v.lvl, v.crv, (unsigned)pd.b, 0u};
+  PairDesc<LDS> D{v.lvl, v.crv, (unsigned)pd.b, 0u, 0u, 0u};
   if (LDS) {  // stage the pair's level and curve descriptors (16 B each) once per workgroup
     Lvl const *const gl = reinterpret_cast<Lvl const *>(v.lvl) + pd.b;
     Lvl const first = gl[0], last = gl[pd.a - 1];
@@ -704,6 +745,13 @@ __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t 
     Crv const *const gc = reinterpret_cast<Crv const *>(v.crv) + first.c0;
     for (int i = threadIdx.x; i < pd.a; i += blockDim.x) sl[i] = gl[i];
     for (int i = threadIdx.x; i < ncrv; i += blockDim.x) sc[i] = gc[i];
+    if (RCPB) {  // reciprocal widths of the p and T brackets (entries that straddle two axes are never used)
+      D.rp_off = (unsigned)((JUR_TBLNP + v.max_pair_curves) * 16);
+      D.rt_off = D.rp_off + (unsigned)(JUR_TBLNP * 8);
+      double *const rp = reinterpret_cast<double *>(jur_lds + D.rp_off), *const rt = reinterpret_cast<double *>(jur_lds + D.rt_off);
+      for (int i = threadIdx.x; i + 1 < pd.a; i += blockDim.x) rp[i] = 1. / (gl[i + 1].p - gl[i].p);
+      for (int i = threadIdx.x; i + 1 < ncrv; i += blockDim.x) rt[i] = 1. / (gc[i + 1].t - gc[i].t);
+    }
     __syncthreads();
   }
   if (r >= c.n) return;
@@ -716,15 +764,13 @@ __global__ __launch_bounds__(256) void jur_ega_kernel(jur_view_t v, jur_chunk_t 
   int const np = c.np[r];
   double tau_path = 1.0;
   unsigned br = 0, ia = 0, ib = 0;
-  double pn = 0, tn = 0, un = 0;
-  if (np > 0) { pn = ldg<double>(los_p, r); tn = ldg<double>(los_t, r); un = ldg<double>(los_u, r); }
   for (int ip = 0; ip < np; ++ip) {
-    double const p = pn, t = tn, u = un;
-    if (ip + 1 < np) {  // the next segment's state is requested before this segment's table work (6 VGPRs, -1 %)
-      size_t const o = (size_t)(ip + 1) * R;
-      pn = ldg<double>(los_p + o, r); tn = ldg<double>(los_t + o, r); un = ldg<double>(los_u + o, r);
-    }
-    double const eps = ega_eps<WARM, LDS>(v, pair_idx, D, tau_path, t, u, p, br, ia, ib);
+    // (requesting the next segment's p, T, u a segment ahead costs 6 VGPRs = one wave per SIMD: 62.6 vs 60.9 ms)
+    size_t const o = (size_t)ip * R;
+    double const p = ldg<double>(los_p + o, r), t = ldg<double>(los_t + o, r), u = ldg<double>(los_u + o, r);
+    double eps;
+    if constexpr (WARM) eps = ega_eps_warm<LDS, RCPB>(v, pair_idx, D, tau_path, t, u, p, br, ia, ib);
+    else eps = ega_eps_exact<LDS>(v, pair_idx, D, tau_path, t, u, p);
     tau_path *= eps;
     *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)((unsigned)r * 8u)) = eps;
   }
@@ -900,14 +946,17 @@ extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *
   unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * npair);
   hipStream_t s = (hipStream_t)stream;
   // LDS copy of one pair's descriptors per workgroup: 16 B x (levels + curves of the largest pair)
-  size_t const lds = sizeof(jur_lvl_t) * JUR_TBLNP + sizeof(jur_crv_t) * (size_t)v->max_pair_curves;
-  bool const use_lds = v->max_pair_curves > 0 && lds <= 32 * 1024 && !getenv("JUR_EGA_NO_LDS");
+  // (+ 8 B x the same counts for the reciprocal bracket widths when the p and T axes are strictly increasing)
+  size_t const lds = (sizeof(jur_lvl_t) + 8) * JUR_TBLNP + (sizeof(jur_crv_t) + 8) * (size_t)v->max_pair_curves;
+  bool const use_lds = v->max_pair_curves > 0 && lds <= 48 * 1024 && !getenv("JUR_EGA_NO_LDS");
+  bool const rcpb = use_lds && v->strict_axes && !getenv("JUR_EGA_NO_RCP");
   if (v->sorted_tables) {
-    if (use_lds) hipLaunchKernelGGL((jur_ega_kernel<true, true>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
-    else hipLaunchKernelGGL((jur_ega_kernel<true, false>), dim3(grid), dim3(block), 0, s, *v, *c, nrb);
+    if (rcpb) hipLaunchKernelGGL((jur_ega_kernel<true, true, true>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
+    else if (use_lds) hipLaunchKernelGGL((jur_ega_kernel<true, true, false>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
+    else hipLaunchKernelGGL((jur_ega_kernel<true, false, false>), dim3(grid), dim3(block), 0, s, *v, *c, nrb);
   } else {
-    if (use_lds) hipLaunchKernelGGL((jur_ega_kernel<false, true>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
-    else hipLaunchKernelGGL((jur_ega_kernel<false, false>), dim3(grid), dim3(block), 0, s, *v, *c, nrb);
+    if (use_lds) hipLaunchKernelGGL((jur_ega_kernel<false, true, false>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
+    else hipLaunchKernelGGL((jur_ega_kernel<false, false, false>), dim3(grid), dim3(block), 0, s, *v, *c, nrb);
   }
   return (int)hipGetLastError();
 }

@@ -326,7 +326,7 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
   out->ue = (jur_ue_t *)calloc(nentry + 2, sizeof(jur_ue_t));
   if (!out->pair || !out->lvl || !out->crv || !out->ue) { jur_flat_free(out); return JUR_ENOMEM; }
   long L = 0, K = 0, E = 0;
-  int sorted = 1;
+  int sorted = 1, strict = 1;
   for (long i = 0; i < npair; i++) {
     jur_pair_t const *pr = &tb->pair[i];
     out->pair[i].a = pr->np;
@@ -336,12 +336,14 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
       out->lvl[L].nt = pr->lv[ip].nt;
       out->lvl[L].c0 = (int)K;
       if (ip > 0 && !(pr->lv[ip - 1].p <= pr->lv[ip].p)) sorted = 0;
+      if (ip > 0 && !(pr->lv[ip - 1].p < pr->lv[ip].p)) strict = 0;
       for (int it = 0; it < pr->lv[ip].nt; it++, K++) {
         jur_curve_t const *cv = &pr->lv[ip].cv[it];
         out->crv[K].t = cv->t;
         out->crv[K].nu = cv->nu;
         out->crv[K].e0 = (int)E;
         if (it > 0 && !(pr->lv[ip].cv[it - 1].t <= cv->t)) sorted = 0;
+        if (it > 0 && !(pr->lv[ip].cv[it - 1].t < cv->t)) strict = 0;
         for (int iu = 0; iu < cv->nu; iu++, E++) {
           out->ue[E].u = cv->u[iu];
           out->ue[E].eps = cv->eps[iu];
@@ -351,6 +353,7 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
     }
   }
   out->sorted = sorted;
+  out->strict_axes = sorted && strict;
   out->max_pair_curves = 0;
   for (long i = 0; i < npair; i++) {
     int nc = 0;
