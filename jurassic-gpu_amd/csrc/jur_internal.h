@@ -55,8 +55,8 @@ typedef struct {
                                    finds what the reference's bisection finds                  */
   int atm_maxslice;             /* longest run of equal time stamps in the atmosphere          */
   int max_pair_curves;          /* most curves any (gas, channel) pair has (LDS staging size)  */
-  int strict_axes;              /* sorted, and the p and T axes strictly increasing: the blends may divide by
-                                   multiplying with reciprocal bracket widths                                   */
+  int strict_tables;            /* sorted, and p, T axes and (as stored, fp32) all curves strictly increasing:
+                                   no bracket of the look-up has zero width                                     */
   /* atmosphere, compact SoA of atm_np points */
   int atm_np;
   int atm_sorted;               /* time stamps non-decreasing and z strictly monotone inside every slice */
@@ -130,7 +130,7 @@ struct jur_tables {
 typedef struct {
   long nlevel, ncurve, nentry;
   int sorted;                   /* all axes and curves non-decreasing           */
-  int strict_axes;              /* ... and p, T axes strictly increasing        */
+  int strict;                   /* ... strictly increasing, curves as stored     */
   int max_pair_curves;
   jur_int2 *pair;
   jur_lvl_t *lvl;

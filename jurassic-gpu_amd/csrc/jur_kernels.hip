@@ -57,6 +57,23 @@ __device__ __forceinline__ double lip_rcp(double x0, double y0, double x1, doubl
   return y0 + div_rcp((x - x0) * (y1 - y0), x1 - x0, r);
 }
 
+// a / b for finite a and finite b != 0 whose exponents are nowhere near the ends of the fp64 range
+// (bracket widths of validated tables, emissivities, column densities, 1e-9 <= tau <= 1): the compiler's
+// fp64 division is rcp + two Newton steps + quotient + residual correction, wrapped in v_div_scale /
+// v_div_fmas (exponent rescaling) and v_div_fixup (zero, infinity, NaN, denormal results).  For such
+// operands the wrapping is the identity, so the bare sequence returns the same double in 8 instead of
+// 11 instructions.
+__device__ __forceinline__ double div_finite(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+  double const q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double lip_finite(double x0, double y0, double x1, double y1, double x) {
+  return y0 + div_finite((x - x0) * (y1 - y0), x1 - x0);
+}
+
 __device__ __forceinline__ double eip(double x0, double y0, double x1, double y1, double x) {
   if ((y0 > 0) && (y1 > 0)) return y0 * exp(log(y1 / y0) / (x1 - x0) * (x - x0));
   return lip(x0, y0, x1, y1, x);
@@ -597,8 +614,9 @@ __device__ __forceinline__ double ega_eps_exact(jur_view_t const &v, int pair_id
 // The two pressure levels are handled one after the other by a rolled loop, two curves (the temperature
 // bracket of the level) at a time: half the curve state is live, 72 VGPRs, 7 waves per SIMD (-5 %
 // against all four curves side by side at 88 VGPRs).
-// RCPB (LDS copy present, p and T axes strictly increasing): the three blends divide by multiplying with
-// the reciprocal bracket widths staged in LDS (div_rcp) -- 3 of the look-up's 12 fp64 divisions.
+// RCPB (LDS copy present; p and T axes and, as stored in fp32, every curve strictly increasing: no bracket
+// has zero width): the three blends divide by multiplying with the reciprocal bracket widths staged in
+// LDS (div_rcp), the other nine divisions use div_finite.
 template <bool LDS, bool RCPB>
 __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, int pair_idx, PairDesc<LDS> const &D, double tau, double t,
                                                double u, double p, unsigned &br, unsigned &ia, unsigned &ib) {
@@ -651,11 +669,15 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, int pair_idx
 #pragma unroll
     for (int k = 0; k < 2; k++) seek_curve<true>(ueb, e0[k], n[k], eps, i[k], a[k], b[k]);
 #pragma unroll
-    for (int k = 0; k < 2; k++) x[k] = lip((double)a[k].eps, (double)a[k].u, (double)b[k].eps, (double)b[k].u, eps) + u;
+    for (int k = 0; k < 2; k++)
+      x[k] = (RCPB ? lip_finite((double)a[k].eps, (double)a[k].u, (double)b[k].eps, (double)b[k].u, eps)
+                   : lip((double)a[k].eps, (double)a[k].u, (double)b[k].eps, (double)b[k].u, eps)) + u;
 #pragma unroll
     for (int k = 0; k < 2; k++) seek_curve<false>(ueb, e0[k], n[k], x[k], i[k], a[k], b[k]);
 #pragma unroll
-    for (int k = 0; k < 2; k++) ec[k] = c01(lip((double)a[k].u, (double)a[k].eps, (double)b[k].u, (double)b[k].eps, x[k]));
+    for (int k = 0; k < 2; k++)
+      ec[k] = c01(RCPB ? lip_finite((double)a[k].u, (double)a[k].eps, (double)b[k].u, (double)b[k].eps, x[k])
+                       : lip((double)a[k].u, (double)a[k].eps, (double)b[k].u, (double)b[k].eps, x[k]));
     unsigned const last = (unsigned)i[0] | ((unsigned)i[1] << 16);
     if (h) ib = last; else ia = last;
     double e;
@@ -663,10 +685,8 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, int pair_idx
     else e = c01(lip(ca.t, ec[0], cb.t, ec[1], t));
     if (h) eps_p1 = e; else eps_p0 = e;
   }
-  double eps_t;
-  if constexpr (RCPB) eps_t = c01(lip_rcp(l0.p, eps_p0, l1.p, eps_p1, p, D.rp(ipr)));
-  else eps_t = c01(lip(l0.p, eps_p0, l1.p, eps_p1, p));
-  return (1. - eps_t) / tau;
+  if constexpr (RCPB) return div_finite(1. - c01(lip_rcp(l0.p, eps_p0, l1.p, eps_p1, p, D.rp(ipr))), tau);
+  return (1. - c01(lip(l0.p, eps_p0, l1.p, eps_p1, p))) / tau;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -946,10 +966,10 @@ extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *
   unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * npair);
   hipStream_t s = (hipStream_t)stream;
   // LDS copy of one pair's descriptors per workgroup: 16 B x (levels + curves of the largest pair)
-  // (+ 8 B x the same counts for the reciprocal bracket widths when the p and T axes are strictly increasing)
+  // (+ 8 B x the same counts for the reciprocal bracket widths of strictly increasing tables)
   size_t const lds = (sizeof(jur_lvl_t) + 8) * JUR_TBLNP + (sizeof(jur_crv_t) + 8) * (size_t)v->max_pair_curves;
   bool const use_lds = v->max_pair_curves > 0 && lds <= 48 * 1024 && !getenv("JUR_EGA_NO_LDS");
-  bool const rcpb = use_lds && v->strict_axes && !getenv("JUR_EGA_NO_RCP");
+  bool const rcpb = use_lds && v->strict_tables && !getenv("JUR_EGA_NO_RCP");
   if (v->sorted_tables) {
     if (rcpb) hipLaunchKernelGGL((jur_ega_kernel<true, true, true>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
     else if (use_lds) hipLaunchKernelGGL((jur_ega_kernel<true, true, false>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);

@@ -145,7 +145,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   if (!rc) rc = upload(&m->d_crv, fl.crv, sizeof(jur_crv_t) * (fl.ncurve + 2));
   if (!rc) rc = upload(&m->d_ue, fl.ue, sizeof(jur_ue_t) * (fl.nentry + 2));
   v->sorted_tables = fl.sorted;
-  v->strict_axes = fl.strict_axes;
+  v->strict_tables = fl.strict;
   v->max_pair_curves = fl.max_pair_curves;
   m->table_bytes = (long)(sizeof(jur_ue_t) * fl.nentry + 16 * fl.ncurve + 16 * fl.nlevel + 8 * npair);
   jur_flat_free(&fl);

@@ -348,12 +348,13 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
           out->ue[E].u = cv->u[iu];
           out->ue[E].eps = cv->eps[iu];
           if (iu > 0 && !(cv->u[iu - 1] <= cv->u[iu] && cv->eps[iu - 1] <= cv->eps[iu])) sorted = 0;
+          if (iu > 0 && !(cv->u[iu - 1] < cv->u[iu] && cv->eps[iu - 1] < cv->eps[iu])) strict = 0;   /* as stored: fp32 */
         }
       }
     }
   }
   out->sorted = sorted;
-  out->strict_axes = sorted && strict;
+  out->strict = sorted && strict;
   out->max_pair_curves = 0;
   for (long i = 0; i < npair; i++) {
     int nc = 0;

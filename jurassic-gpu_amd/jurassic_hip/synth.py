@@ -14,14 +14,16 @@ RE = 6367.421
 K0 = {"CO2": 5e-23, "H2O": 2e-22, "O3": 5e-21, "F11": 1e-17, "CCL4": 2e-17}
 
 
-def table_rows(emitter, nu, id_=0, nlev=33, ntemp=10, descending=False, umax_eps=0.99999, ratio=1.122):
+def table_rows(emitter, nu, id_=0, nlev=33, ntemp=10, descending=False, umax_eps=0.99999, ratio=1.122, dup_every=0):
     """Rows (p, T, u, eps) of one synthetic table in file order.
 
     p: nlev levels 0.016..1000 hPa (log-spaced, ascending unless `descending`);
     T: ntemp values per level, 15 K apart, the axis shifted by 2 K*(level%3) so
        neighbouring levels do not share their temperature brackets;
     u: geometric grid with the given ratio from eps~1e-6 to eps>umax_eps;
-    eps = 1 - exp(-(k u)^0.7), k = k0 sqrt(p/1000) 250/T (1+0.3 id_) (nu/800)^2."""
+    eps = 1 - exp(-(k u)^0.7), k = k0 sqrt(p/1000) 250/T (1+0.3 id_) (nu/800)^2;
+    dup_every = k > 0: after every k-th row a row 1e-10 (relative) above it -- larger as a double, so the
+       loader keeps it, equal once stored as fp32: curves that are sorted but not strictly increasing."""
     k0 = K0.get(emitter.upper(), 1e-21) * (1 + 0.3 * id_) * (nu / 800.0) ** 2
     plev = np.exp(np.linspace(np.log(0.016), np.log(1000.0), nlev))
     if descending:
@@ -42,6 +44,10 @@ def table_rows(emitter, nu, id_=0, nlev=33, ntemp=10, descending=False, umax_eps
             blk[:, 1] = t
             blk[:, 2] = u[:n]
             blk[:, 3] = eps[:n]
+            if dup_every > 0:
+                twin = blk[dup_every - 1::dup_every].copy()
+                twin[:, 2:] *= 1.0 + 1e-10
+                blk = np.insert(blk, np.arange(dup_every, n + 1, dup_every)[:len(twin)], twin, axis=0)
             blocks.append(blk)
     return np.vstack(blocks)
 

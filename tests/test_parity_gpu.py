@@ -121,10 +121,26 @@ def test_nan_mask(hip, oracle):
                                 dict(table_kw=dict(ntemp=1)),                    # nt < 2 -> transparent
                                 dict(table_kw=dict(umax_eps=-1.0)),              # nu < 2 -> transparent
                                 dict(table_kw=dict(nlev=40, ntemp=30, ratio=1.08)),   # maximum extents (TBLNU clips)
+                                dict(table_kw=dict(dup_every=7)),                # sorted, not strict: zero-width fp32 brackets
                                 dict(missing={(0, 1), (2, 0), (3, 0), (3, 1)})])
 def test_table_shapes(hip, oracle, kw):
     out, ref = run_both(hip, oracle, common.limb_case(geom=synth.limb_geometry(200, seed=9), **kw))
     assert_parity(out, ref)
+
+
+def test_division_paths_return_the_same_doubles(hip, monkeypatch):
+    """Strictly increasing tables let jur_ega_kernel divide through reciprocal bracket widths and the bare
+    division sequence; JUR_EGA_NO_RCP=1 selects the compiler's fp64 division.
+    Same doubles, bit for bit."""
+    case = common.limb_case(geom=synth.limb_geometry(3000, seed=4, nprofiles=8), nu=common.CTM4_NU, nprofiles=8)
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    fast = model.formod_host(case.geom)
+    monkeypatch.setenv("JUR_EGA_NO_RCP", "1")
+    ieee = model.formod_host(case.geom)
+    model.close()
+    for k in ("rad", "tau"):
+        assert np.array_equal(fast[k].view(np.uint64), ieee[k].view(np.uint64)), k
 
 
 def test_curtis_godson_columns(hip, oracle):
