@@ -25,12 +25,13 @@ typedef struct {
   double co2_cw296, co2_cw260, co2_cw230;   /* 2 cm^-1 grid interpolates            */
   double h2o_sc;                            /* sfac * cw296                         */
   double h2o_ratio;                         /* cw260 / cw296                        */
+  double h2o_lnr_hi, h2o_lnr_lo;            /* ln(h2o_ratio) = hi + lo (from logl), for ratio^y = exp(y ln ratio) */
   double h2o_ctwfrn;                        /* cwfrn * fscal                        */
   double n2_b, n2_beta;
   double o2_b, o2_beta;
   int co2_on, h2o_on, n2_on, o2_on;         /* channel inside the continuum's range */
   int window;
-  int pad;
+  int h2o_lnr_ok;                           /* ratio finite, positive, normal: the split logarithm is usable */
 } jur_chan_t;
 
 /* LOS workspace: fields stored as [field][point][ray-in-chunk] (ray fastest). */

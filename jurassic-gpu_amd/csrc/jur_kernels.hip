@@ -170,6 +170,16 @@ __global__ void jur_pslope_kernel(int n, double const *__restrict__ z, double co
 // 4 waves per SIMD (128 VGPRs, some scratch): measured 20 % faster than 2 waves without spills once a
 // launch carries enough rays (>= 4 x 131072) to fill them
 __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chunk_t c) {
+  __shared__ double tr_sh[15][64];
+#define TR_PZ tr_sh[0][threadIdx.x]
+#define TR_PX(i) tr_sh[1 + (i)][threadIdx.x]
+#define TR_LZ0 tr_sh[4][threadIdx.x]
+#define TR_LX0(i) tr_sh[5 + (i)][threadIdx.x]
+#define TR_LZ1 tr_sh[8][threadIdx.x]
+#define TR_LDS1 tr_sh[9][threadIdx.x]
+#define TR_LZ2 tr_sh[10][threadIdx.x]
+#define TR_LX2(i) tr_sh[11 + (i)][threadIdx.x]
+#define TR_LDS2 tr_sh[14][threadIdx.x]
   int const r = blockIdx.x * blockDim.x + threadIdx.x;   // slot in the chunk
   if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
@@ -239,13 +249,15 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
     // latitude of a LOS point are only ever needed for the point before the exit (clipping), the two
     // neighbours of the lowest point and the last point, so the per-step asin/atan2 of cart2geo is
     // deferred: the Cartesian position is kept and converted on demand (same input, same result).
+    // This bookkeeping is written often and read a few times per ray; it lives in LDS (one column per
+    // lane) so that its 30 registers stay free for the loop: the kernel is latency-bound and was
+    // spilling to scratch, whose stores queue in front of the profile loads (one vmcnt for both).
     double z_low = 1e99;
     int low_idx = -1;
-    double pz = 0, px[3] = {0, 0, 0};                       // previous point (np-1)
-    double lz0 = 0, lx0[3] = {0, 0, 0};                     // point low_idx-1
-    double lz1 = 0, lds1 = 0;                               // point low_idx
-    double lz2 = 0, lx2[3] = {0, 0, 0}, lds2 = 0;           // point low_idx+1
-    double last_z = 0;
+    TR_PZ = 0; TR_PX(0) = 0; TR_PX(1) = 0; TR_PX(2) = 0;    // previous point (np-1)
+    TR_LZ0 = 0; TR_LX0(0) = 0; TR_LX0(1) = 0; TR_LX0(2) = 0;   // point low_idx-1
+    TR_LZ1 = 0; TR_LDS1 = 0;                                 // point low_idx
+    TR_LZ2 = 0; TR_LX2(0) = 0; TR_LX2(1) = 0; TR_LX2(2) = 0; TR_LDS2 = 0;   // point low_idx+1
 
     // altitude brackets are resumed from the previous point when the slice's axis is strictly monotone
     int const zdir = (v.atm_sorted && atmn >= 2) ? ((v.atm_z[atm0] < v.atm_z[atm0 + 1]) ? 1 : -1) : 0;
@@ -274,6 +286,7 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
         stop = (z < zmin) ? 2 : 1;
         if (np > 0) {
           double pzz, plon, plat;
+          double const px[3] = {TR_PX(0), TR_PX(1), TR_PX(2)}, pz = TR_PZ;
           cart2geo(px, pzz, plon, plat);   // == the previous point's stored geolocation upstream
           geo2cart(pz, plon, plat, xh);
           double const zfrac = (z < zmin) ? zmin : zmax;
@@ -282,8 +295,8 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
           z = norm3(x) - JUR_RE;
           double const dsp = ds * frac;
           if (fused) ds_p = dsp; else F(JUR_F_DS, np - 1) = dsp;
-          if (low_idx == np - 1) lds1 = dsp;
-          if (low_idx + 1 == np - 1) lds2 = dsp;
+          if (low_idx == np - 1) TR_LDS1 = dsp;
+          if (low_idx + 1 == np - 1) TR_LDS2 = dsp;
         }
         ds = 0.;
       }
@@ -328,17 +341,16 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
       if (fused) { ds_pp = ds_p; ds_p = ds; p_p = p; t_p = t; }
       else F(JUR_F_DS, np) = ds;
 
-      if (low_idx >= 0 && low_idx == np - 1) { lz2 = z; lds2 = ds; for (int i = 0; i < 3; i++) lx2[i] = x[i]; }
+      if (low_idx >= 0 && low_idx == np - 1) { TR_LZ2 = z; TR_LDS2 = ds; for (int i = 0; i < 3; i++) TR_LX2(i) = x[i]; }
       if (z < z_low) {
         z_low = z;
         low_idx = np;
-        lz0 = pz;
-        for (int i = 0; i < 3; i++) lx0[i] = px[i];
-        lz1 = z; lds1 = ds;
+        TR_LZ0 = TR_PZ;
+        for (int i = 0; i < 3; i++) TR_LX0(i) = TR_PX(i);
+        TR_LZ1 = z; TR_LDS1 = ds;
       }
-      last_z = z;
-      pz = z;
-      for (int i = 0; i < 3; i++) px[i] = x[i];
+      TR_PZ = z;                          // also the last point's altitude after the loop
+      for (int i = 0; i < 3; i++) TR_PX(i) = x[i];
 
       if (stop) {
         tsurf = (stop == 2 ? t : -999);
@@ -392,10 +404,13 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
     // tangent point from the raw segment lengths (jr_common.h:502-539)
     if (low_idx <= 0 || low_idx >= np - 1) {
       double zz;
-      cart2geo(px, zz, tplon, tplat);   // px is the last point here
-      tpz = last_z;
+      double const px[3] = {TR_PX(0), TR_PX(1), TR_PX(2)};   // the last point here
+      cart2geo(px, zz, tplon, tplat);
+      tpz = TR_PZ;
     } else {
-      double const yy0 = lz0, yy1 = lz1, yy2 = lz2, ds0 = lds1, ds1 = lds2,
+      double const lz0 = TR_LZ0, lz2 = TR_LZ2;
+      double const lx0[3] = {TR_LX0(0), TR_LX0(1), TR_LX0(2)}, lx2[3] = {TR_LX2(0), TR_LX2(1), TR_LX2(2)};
+      double const yy0 = lz0, yy1 = TR_LZ1, yy2 = lz2, ds0 = TR_LDS1, ds1 = TR_LDS2,
                    dyy10 = yy1 - yy0, dyy21 = yy2 - yy1,
                    x1 = sqrt(ds0 * ds0 - dyy10 * dyy10),
                    x2 = x1 + sqrt(ds1 * ds1 - dyy21 * dyy21),
@@ -444,6 +459,16 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
   c.tp[1][ray] = tplon;
   c.tp[2][ray] = tplat;
 }
+
+#undef TR_PZ
+#undef TR_PX
+#undef TR_LZ0
+#undef TR_LX0
+#undef TR_LZ1
+#undef TR_LDS1
+#undef TR_LZ2
+#undef TR_LX2
+#undef TR_LDS2
 
 // ---------------------------------------------------------------------------------------
 // emissivity-growth look-up (ega_eps, jr_common.h:237-268)
@@ -701,8 +726,19 @@ __device__ __forceinline__ double ctm_co2(jur_chan_t const &ch, double p, double
   return u * p * ctw / (JUR_AVOGADRO * 1000 * JUR_P0);
 }
 
+// ratio^y for a per-channel constant ratio: exp(y ln ratio) with ln ratio = hi + lo prepared on the host
+// (64-bit logarithm) and the product y ln ratio carried with its rounding error -- about 1 ulp like the
+// library's pow, which spends most of its ~180 instructions on that logarithm.
+__device__ __forceinline__ double pow_const(double lnr_hi, double lnr_lo, double y) {
+  double const ph = y * lnr_hi;
+  double const pl = __builtin_fma(y, lnr_hi, -ph) + y * lnr_lo;
+  double const e = exp(ph);
+  return __builtin_fma(e, pl, e);
+}
+
 __device__ __forceinline__ double ctm_h2o(jur_chan_t const &ch, double p, double t, double q, double u) {
-  double const ctwslf = ch.h2o_sc * pow(ch.h2o_ratio, (296. - t) / (296. - 260.));
+  double const y = (296. - t) / (296. - 260.);
+  double const ctwslf = ch.h2o_sc * (ch.h2o_lnr_ok ? pow_const(ch.h2o_lnr_hi, ch.h2o_lnr_lo, y) : pow(ch.h2o_ratio, y));
   double const a1 = ch.nu * u * tanh(.7193876 / t * ch.nu);
   double const a2 = 296. / t;
   double const a3 = p / JUR_P0 * (q * ctwslf + (1 - q) * ch.h2o_ctwfrn) * 1e-20;

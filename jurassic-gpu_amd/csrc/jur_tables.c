@@ -90,6 +90,12 @@ void jur_chan_setup(jur_chan_t *ch, double nu, int window) {
     ch->h2o_on = 1;
     ch->h2o_sc = sfac * cw296;
     ch->h2o_ratio = cw260 / cw296;
+    if (isnormal(ch->h2o_ratio) && ch->h2o_ratio > 0) {  /* ln(ratio) to 64 bits, split into two doubles */
+      long double const l = logl((long double)ch->h2o_ratio);
+      ch->h2o_lnr_hi = (double)l;
+      ch->h2o_lnr_lo = (double)(l - (long double)ch->h2o_lnr_hi);
+      ch->h2o_lnr_ok = 1;
+    }
     ch->h2o_ctwfrn = cwfrn * fscal;
   }
   if (!(nu < 2120 || nu > 2605)) {                      /* N2, 5 cm^-1 grid, 98 entries */
