@@ -717,13 +717,21 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, int pair_idx
 // ---------------------------------------------------------------------------------------
 // continua; the channel-only factors come precomputed in jur_chan_t
 // ---------------------------------------------------------------------------------------
+// a / C for a compile-time constant C: the quotient through r = RN(1/C) (div_rcp), folded by the compiler
+struct CO2_DEN { static constexpr double v = JUR_AVOGADRO * 1000 * JUR_P0; };
+struct P0_DEN { static constexpr double v = JUR_P0; };
+struct T36_DEN { static constexpr double v = 296. - 260.; };
+struct TR_DEN { static constexpr double v = 296.; };
+template <class C>
+__device__ __forceinline__ double div_const(double a) { return div_rcp(a, C::v, 1. / C::v); }
+
 __device__ __forceinline__ double ctm_co2(jur_chan_t const &ch, double p, double t, double u) {
   double const dt230 = t - 230;
   double const dt260 = t - 260;
   double const dt296 = t - 296;
   double const ctw = dt260 * 5.050505e-4 * dt296 * ch.co2_cw230 - dt230 * 9.259259e-4 * dt296 * ch.co2_cw260
                    + dt230 * 4.208754e-4 * dt260 * ch.co2_cw296;
-  return u * p * ctw / (JUR_AVOGADRO * 1000 * JUR_P0);
+  return div_const<CO2_DEN>(u * p * ctw);
 }
 
 // ratio^y for a per-channel constant ratio: exp(y ln ratio) with ln ratio = hi + lo prepared on the host
@@ -737,23 +745,25 @@ __device__ __forceinline__ double pow_const(double lnr_hi, double lnr_lo, double
 }
 
 __device__ __forceinline__ double ctm_h2o(jur_chan_t const &ch, double p, double t, double q, double u) {
-  double const y = (296. - t) / (296. - 260.);
+  double const y = div_const<T36_DEN>(296. - t);
   double const ctwslf = ch.h2o_sc * (ch.h2o_lnr_ok ? pow_const(ch.h2o_lnr_hi, ch.h2o_lnr_lo, y) : pow(ch.h2o_ratio, y));
   double const a1 = ch.nu * u * tanh(.7193876 / t * ch.nu);
   double const a2 = 296. / t;
-  double const a3 = p / JUR_P0 * (q * ctwslf + (1 - q) * ch.h2o_ctwfrn) * 1e-20;
+  double const a3 = div_const<P0_DEN>(p) * (q * ctwslf + (1 - q) * ch.h2o_ctwfrn) * 1e-20;
   return a1 * a2 * a3;
 }
 
 __device__ __forceinline__ double ctm_n2(jur_chan_t const &ch, double p, double t) {
   double const q_n2 = 0.79, t0 = 273, tr = 296;
-  return 0.1 * (p / JUR_P0) * (p / JUR_P0) * (t0 / t) * (t0 / t) * exp(ch.n2_beta * (1 / tr - 1 / t)) * q_n2 * ch.n2_b
-         * (q_n2 + (1 - q_n2) * (1.294 - 0.4545 * t / tr));
+  double const pr = div_const<P0_DEN>(p);
+  return 0.1 * pr * pr * (t0 / t) * (t0 / t) * exp(ch.n2_beta * (1 / tr - 1 / t)) * q_n2 * ch.n2_b
+         * (q_n2 + (1 - q_n2) * (1.294 - div_const<TR_DEN>(0.4545 * t)));
 }
 
 __device__ __forceinline__ double ctm_o2(jur_chan_t const &ch, double p, double t) {
   double const q_o2 = 0.21, t0 = 273, tr = 296;
-  return 0.1 * (p / JUR_P0) * (p / JUR_P0) * (t0 / t) * (t0 / t) * exp(ch.o2_beta * (1 / tr - 1 / t)) * q_o2 * ch.o2_b;
+  double const pr = div_const<P0_DEN>(p);
+  return 0.1 * pr * pr * (t0 / t) * (t0 / t) * exp(ch.o2_beta * (1 / tr - 1 / t)) * q_o2 * ch.o2_b;
 }
 
 __device__ __forceinline__ double planck_src(double const *__restrict__ sr, double t) {
