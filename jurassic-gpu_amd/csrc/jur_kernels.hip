@@ -770,9 +770,10 @@ __device__ __forceinline__ double planck_src(double const *__restrict__ sr, doub
   // 0.25 K grid from 100 K (locate_st, jr_common.h:82-84).  Upstream has no range check and reads
   // outside the table for T outside [100, 400) K; here the index is clamped (end intervals extrapolate).
   int const it = min(max((int)(4 * t) - 400, 0), TBLNS - 2);
-  double const st0 = 100 + ((double)it - 0.0) * (400 - 100) / ((TBLNS - 1.0) - 0.0);
-  double const st1 = 100 + ((double)(it + 1) - 0.0) * (400 - 100) / ((TBLNS - 1.0) - 0.0);
-  return lip(st0, sr[it], st1, sr[it + 1], t);
+  // grid points 100 + it * 300 / 1200 are multiples of 0.25: exact doubles, and the bracket width
+  // st1 - st0 is exactly 0.25, so the interpolation's division is the exact multiplication by 4
+  double const st0 = 100 + 0.25 * (double)it;
+  return sr[it] + (t - st0) * (sr[it + 1] - sr[it]) * 4.0;
 }
 
 // ---------------------------------------------------------------------------------------
