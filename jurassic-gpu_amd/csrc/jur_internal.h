@@ -31,7 +31,7 @@ typedef struct {
   double o2_b, o2_beta;
   int co2_on, h2o_on, n2_on, o2_on;         /* channel inside the continuum's range */
   int window;
-  int h2o_lnr_ok;                           /* ratio finite, positive, normal: the split logarithm is usable */
+  int pad;
 } jur_chan_t;
 
 /* LOS workspace: fields stored as [field][point][ray-in-chunk] (ray fastest). */
@@ -142,7 +142,7 @@ int  jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out);
 void jur_flat_free(jur_flat_t *f);
 
 void jur_tables_cache_filename(char *out, size_t len, ctl_t const *ctl);
-void jur_chan_setup(jur_chan_t *ch, double nu, int window);
+int jur_chan_setup(jur_chan_t *ch, double nu, int window);
 void jur_set_error(char const *fmt, ...);
 
 extern const double jur_ctm_blob[] __attribute__((visibility("hidden")));

@@ -746,7 +746,7 @@ __device__ __forceinline__ double pow_const(double lnr_hi, double lnr_lo, double
 
 __device__ __forceinline__ double ctm_h2o(jur_chan_t const &ch, double p, double t, double q, double u) {
   double const y = div_const<T36_DEN>(296. - t);
-  double const ctwslf = ch.h2o_sc * (ch.h2o_lnr_ok ? pow_const(ch.h2o_lnr_hi, ch.h2o_lnr_lo, y) : pow(ch.h2o_ratio, y));
+  double const ctwslf = ch.h2o_sc * pow_const(ch.h2o_lnr_hi, ch.h2o_lnr_lo, y);
   double const a1 = ch.nu * u * tanh(.7193876 / t * ch.nu);
   double const a2 = 296. / t;
   double const a3 = div_const<P0_DEN>(p) * (q * ctwslf + (1 - q) * ch.h2o_ctwfrn) * 1e-20;
@@ -845,7 +845,8 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
 
 // jur_combine_kernel: one lane per ray, one channel per workgroup: continua, product of the gas
 // transmittances in the reference's order, Planck source, radiance update, epilogue.
-__global__ __launch_bounds__(256) void jur_combine_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
+// 6 waves per SIMD: 18.2 ms per 1e6 limb rays against 20.6 ms at 4 and 20.4 ms at 7
+__global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
   int const nd = v.nd, ng = v.ng;
   // same XCD-aware order as jur_ega_kernel: the nd workgroups of one ray block follow each other
   // on one XCD and share the block's LOS rows in that L2

@@ -120,7 +120,8 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
              + (1 == ctl->ctm_n2) * 2 + (1 == ctl->ctm_o2) * 1;
 
   jur_chan_t *chan = (jur_chan_t *)calloc(ctl->nd, sizeof(jur_chan_t));
-  for (int id = 0; id < ctl->nd; id++) jur_chan_setup(&chan[id], ctl->nu[id], ctl->window[id]);
+  for (int id = 0; id < ctl->nd; id++)
+    if ((rc = jur_chan_setup(&chan[id], ctl->nu[id], ctl->window[id]))) { free(chan); jur_model_destroy(m); return rc; }
   rc = upload(&m->d_chan, chan, sizeof(jur_chan_t) * ctl->nd);
   free(chan);
   if (rc) { jur_model_destroy(m); return rc; }

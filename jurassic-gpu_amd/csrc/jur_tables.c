@@ -55,7 +55,7 @@ static double grid_lerp(int base, int iw, double ew, double dw) {
 /* Channel-only part of the four continua.  The expressions keep the operand
  * order of jr_common.h:315-390 so the products formed here are the same
  * doubles the reference forms per call. */
-void jur_chan_setup(jur_chan_t *ch, double nu, int window) {
+int jur_chan_setup(jur_chan_t *ch, double nu, int window) {
   memset(ch, 0, sizeof *ch);
   ch->nu = nu;
   ch->window = window;
@@ -90,12 +90,15 @@ void jur_chan_setup(jur_chan_t *ch, double nu, int window) {
     ch->h2o_on = 1;
     ch->h2o_sc = sfac * cw296;
     ch->h2o_ratio = cw260 / cw296;
-    if (isnormal(ch->h2o_ratio) && ch->h2o_ratio > 0) {  /* ln(ratio) to 64 bits, split into two doubles */
-      long double const l = logl((long double)ch->h2o_ratio);
-      ch->h2o_lnr_hi = (double)l;
-      ch->h2o_lnr_lo = (double)(l - (long double)ch->h2o_lnr_hi);
-      ch->h2o_lnr_ok = 1;
+    /* the kernel forms ratio^y as exp(y ln ratio): ln(ratio) to 64 bits, split into two doubles.  The
+     * shipped coefficients are positive everywhere (ratio 1.21 ... 3.67), so the check never fires. */
+    if (!(isnormal(ch->h2o_ratio) && ch->h2o_ratio > 0)) {
+      jur_set_error("H2O continuum: self-broadening ratio %g at %g cm^-1 is not positive", ch->h2o_ratio, nu);
+      return JUR_EINVAL;
     }
+    long double const l = logl((long double)ch->h2o_ratio);
+    ch->h2o_lnr_hi = (double)l;
+    ch->h2o_lnr_lo = (double)(l - (long double)ch->h2o_lnr_hi);
     ch->h2o_ctwfrn = cwfrn * fscal;
   }
   if (!(nu < 2120 || nu > 2605)) {                      /* N2, 5 cm^-1 grid, 98 entries */
@@ -116,6 +119,7 @@ void jur_chan_setup(jur_chan_t *ch, double nu, int window) {
     ch->o2_b = a0 * jur_ctm_blob[B_O2_B + idx] + a1 * jur_ctm_blob[B_O2_B + idx1];
     ch->o2_beta = a0 * jur_ctm_blob[B_O2_BETA + idx] + a1 * jur_ctm_blob[B_O2_BETA + idx1];
   }
+  return JUR_OK;
 }
 
 /* ---- table builder --------------------------------------------------------- */
