@@ -582,10 +582,9 @@ struct PairDesc {
 // EXACT look-up: the reference's bisections probe for probe (locate_id jr_common.h:106-114, locate_tbl_id
 // :116-125), for tables whose axes or curves are not sorted.
 template <bool LDS>
-__device__ __forceinline__ double ega_eps_exact(jur_view_t const &v, int pair_idx, PairDesc<LDS> const &D, double tau, double t,
+__device__ __forceinline__ double ega_eps_exact(jur_view_t const &v, jur_int2 const pr, PairDesc<LDS> const &D, double tau, double t,
                                                 double u, double p) {
   if (tau < 1e-9) return 0.;
-  jur_int2 const pr = v.pair[pair_idx];
   if (pr.a < 2) return 1.;
   void const *const ueb = v.ue;
   int ilo = 0, ihi = pr.a - 1;
@@ -643,11 +642,10 @@ __device__ __forceinline__ double ega_eps_exact(jur_view_t const &v, int pair_id
 // has zero width): the three blends divide by multiplying with the reciprocal bracket widths staged in
 // LDS (div_rcp), the other nine divisions use div_finite.
 template <bool LDS, bool RCPB>
-__device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, int pair_idx, PairDesc<LDS> const &D, double tau, double t,
+__device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 const pr, PairDesc<LDS> const &D, double tau, double t,
                                                double u, double p, unsigned &br, unsigned &ia, unsigned &ib) {
   static_assert(LDS || !RCPB, "the reciprocal widths live in LDS");
   if (tau < 1e-9) return 0.;
-  jur_int2 const pr = v.pair[pair_idx];
   if (pr.a < 2) return 1.;
   void const *const ueb = v.ue;
   int ipr = min((int)(br & 0xffu), pr.a - 2);
@@ -836,8 +834,8 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
     size_t const o = (size_t)ip * R;
     double const p = ldg<double>(los_p + o, r), t = ldg<double>(los_t + o, r), u = ldg<double>(los_u + o, r);
     double eps;
-    if constexpr (WARM) eps = ega_eps_warm<LDS, RCPB>(v, pair_idx, D, tau_path, t, u, p, br, ia, ib);
-    else eps = ega_eps_exact<LDS>(v, pair_idx, D, tau_path, t, u, p);
+    if constexpr (WARM) eps = ega_eps_warm<LDS, RCPB>(v, pd, D, tau_path, t, u, p, br, ia, ib);
+    else eps = ega_eps_exact<LDS>(v, pd, D, tau_path, t, u, p);
     tau_path *= eps;
     *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)((unsigned)r * 8u)) = eps;
   }
