@@ -167,6 +167,21 @@ __global__ void jur_pslope_kernel(int n, double const *__restrict__ z, double co
 // ---------------------------------------------------------------------------------------
 // ray tracing, one lane per ray
 // ---------------------------------------------------------------------------------------
+// Exit clipping (jr_common.h:637-648), once per ray: the previous point is rebuilt from its geodetic
+// coordinates and the last segment is cut at the atmosphere's boundary.  Kept out of line: inlined, the
+// asin/atan2/sin/cos polynomials have their ~40 constants hoisted in front of the stepping loop, where
+// they cost the loop its registers (spills whose reloads queue behind the LOS stores).
+struct ClipOut { double x0, x1, x2, frac; };
+__device__ __attribute__((noinline)) ClipOut clip_exit(double px0, double px1, double px2, double pz, double x0, double x1,
+                                                       double x2, double z, double zfrac) {
+  double const px[3] = {px0, px1, px2};
+  double xh[3], pzz, plon, plat;
+  cart2geo(px, pzz, plon, plat);   // == the previous point's stored geolocation upstream
+  geo2cart(pz, plon, plat, xh);
+  double const frac = (zfrac - pz) / (z - pz);
+  return {xh[0] + frac * (x0 - xh[0]), xh[1] + frac * (x1 - xh[1]), xh[2] + frac * (x2 - xh[2]), frac};
+}
+
 // 4 waves per SIMD (128 VGPRs, some scratch): measured 20 % faster than 2 waves without spills once a
 // launch carries enough rays (>= 4 x 131072) to fill them
 __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chunk_t c) {
@@ -282,16 +297,11 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
       }
       double z = norm3(x) - JUR_RE;
       if ((z < zmin) || (z > zmax)) {  // LOS left the atmosphere: clip the last segment (:637-648)
-        double xh[3];
         stop = (z < zmin) ? 2 : 1;
         if (np > 0) {
-          double pzz, plon, plat;
-          double const px[3] = {TR_PX(0), TR_PX(1), TR_PX(2)}, pz = TR_PZ;
-          cart2geo(px, pzz, plon, plat);   // == the previous point's stored geolocation upstream
-          geo2cart(pz, plon, plat, xh);
-          double const zfrac = (z < zmin) ? zmin : zmax;
-          double const frac = (zfrac - pz) / (z - pz);
-          for (int i = 0; i < 3; i++) x[i] = xh[i] + frac * (x[i] - xh[i]);
+          ClipOut const co = clip_exit(TR_PX(0), TR_PX(1), TR_PX(2), TR_PZ, x[0], x[1], x[2], z, (z < zmin) ? zmin : zmax);
+          x[0] = co.x0; x[1] = co.x1; x[2] = co.x2;
+          double const frac = co.frac;
           z = norm3(x) - JUR_RE;
           double const dsp = ds * frac;
           if (fused) ds_p = dsp; else F(JUR_F_DS, np - 1) = dsp;
