@@ -171,6 +171,20 @@ __global__ void jur_pslope_kernel(int n, double const *__restrict__ z, double co
 // coordinates and the last segment is cut at the atmosphere's boundary.  Kept out of line: inlined, the
 // asin/atan2/sin/cos polynomials have their ~40 constants hoisted in front of the stepping loop, where
 // they cost the loop its registers (spills whose reloads queue behind the LOS stores).
+// The point before the exit gets its segment length only when the exit is found (jr_common.h:645-646):
+// its trapezoid weight and column densities, written provisionally one step earlier, are redone here from
+// the same profile bracket (same inputs, same doubles).  Out of line, once per ray.
+__device__ __attribute__((noinline)) void redo_columns(double const *__restrict__ atm_z, double const *__restrict__ atm_q,
+                                                       int atm_np, int i0, int n, int ng, double z, double p, double t,
+                                                       double dsn, double *__restrict__ los_u, size_t fs) {
+  int const ip = i0 + locate_axis(atm_z + i0, n, z);
+  double const za = atm_z[ip], zb = atm_z[ip + 1];
+  for (int ig = 0; ig < ng; ig++) {
+    double const *q = atm_q + (size_t)ig * atm_np;
+    los_u[(size_t)ig * fs] = 10. * lip(za, q[ip], zb, q[ip + 1], z) * p / (JUR_BOLTZMANN * t) * dsn;
+  }
+}
+
 struct ClipOut { double x0, x1, x2, frac; };
 __device__ __attribute__((noinline)) ClipOut clip_exit(double px0, double px1, double px2, double pz, double x0, double x1,
                                                        double x2, double z, double zfrac) {
@@ -278,11 +292,9 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
     int const zdir = (v.atm_sorted && atmn >= 2) ? ((v.atm_z[atm0] < v.atm_z[atm0 + 1]) ? 1 : -1) : 0;
     int zhint = (zdir > 0) ? atmn - 2 : 0, rhint = zhint;   // rays usually enter at the top
 
-    constexpr int QMAX = 6;
-    bool const fused = v.ng <= QMAX;                       // wave-uniform
-    double ds_p = 0, ds_pp = 0, p_p = 0, t_p = 0, q_p[QMAX];
-#pragma unroll
-    for (int ig = 0; ig < QMAX; ig++) q_p[ig] = 0;
+    // raw segment lengths of the two previous points: the trapezoid rule (jr_common.h:437-443) and the
+    // column densities (:446-453) of a point are written in its own step, ds[i] <- (ds[i-1] + ds[i]) / 2
+    double ds_p = 0, ds_pp = 0;
 
     int stop = 0;
     for (; np < NLOS; ++np) {
@@ -303,43 +315,29 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
           x[0] = co.x0; x[1] = co.x1; x[2] = co.x2;
           double const frac = co.frac;
           z = norm3(x) - JUR_RE;
-          double const dsp = ds * frac;
-          if (fused) ds_p = dsp; else F(JUR_F_DS, np - 1) = dsp;
+          double const dsp = ds * frac;            // the previous point's segment, cut at the boundary
           if (low_idx == np - 1) TR_LDS1 = dsp;
           if (low_idx + 1 == np - 1) TR_LDS2 = dsp;
+          double const dsn = (np >= 2) ? 0.5 * (ds_pp + dsp) : dsp * 0.5;
+          F(JUR_F_DS, np - 1) = dsn;
+          redo_columns(v.atm_z, v.atm_q, v.atm_np, atm0, atmn, v.ng, TR_PZ, F(JUR_F_P, np - 1), F(JUR_F_T, np - 1), dsn,
+                       &F(f_u, np - 1), (size_t)NLOS * R);
+          ds_p = dsp;
         }
         ds = 0.;
       }
 
       double p, t;
       int const ia = intpol_pt(v, atm0, atmn, z, p, t, zdir, zhint);
-      // With few gases the trapezoid rule and the column densities (jr_common.h:437-453) are applied one
-      // point late -- point np-1 is complete once point np has fixed its segment length -- instead of in a
-      // second sweep over the ray's column: its p, T and mixing ratios wait in registers.
-      if (fused && np > 0) {
-        double const dsn = (np >= 2) ? 0.5 * (ds_pp + ds_p) : ds_p * 0.5;   // ds_p already carries a clipping
-        F(JUR_F_DS, np - 1) = dsn;
-#pragma unroll
-        for (int ig = 0; ig < QMAX; ig++)
-          if (ig < v.ng) F(f_u + ig, np - 1) = 10. * q_p[ig] * p_p / (JUR_BOLTZMANN * t_p) * dsn;
-      }
+      double const dsn = (np >= 1) ? 0.5 * (ds_p + ds) : ds * 0.5;   // redone for the point before the exit
+      F(JUR_F_DS, np) = dsn;
       {  // remaining quantities on the same bracket (jr_common.h:557-567)
         double const za = v.atm_z[ia], zb = v.atm_z[ia + 1];
-        if (fused) {
-#pragma unroll
-          for (int ig = 0; ig < QMAX; ig++)
-            if (ig < v.ng) {
-              double const *q = v.atm_q + (size_t)ig * v.atm_np;
-              q_p[ig] = lip(za, q[ia], zb, q[ia + 1], z);
-              if (ig == v.ig_h2o) F(JUR_F_QH2O, np) = q_p[ig];
-            }
-        } else {
-          for (int ig = 0; ig < v.ng; ig++) {
-            double const *q = v.atm_q + (size_t)ig * v.atm_np;
-            double const qv = lip(za, q[ia], zb, q[ia + 1], z);
-            F(f_u + ig, np) = qv;  // mixing ratio now, column density after the trapezoid pass
-            if (ig == v.ig_h2o) F(JUR_F_QH2O, np) = qv;
-          }
+        for (int ig = 0; ig < v.ng; ig++) {
+          double const *q = v.atm_q + (size_t)ig * v.atm_np;
+          double const qv = lip(za, q[ia], zb, q[ia + 1], z);
+          F(f_u + ig, np) = 10. * qv * p / (JUR_BOLTZMANN * t) * dsn;
+          if (ig == v.ig_h2o) F(JUR_F_QH2O, np) = qv;
         }
         for (int iw = 0; iw < v.nw; iw++) {
           double const *k = v.atm_k + (size_t)iw * v.atm_np;
@@ -348,8 +346,7 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
       }
       F(JUR_F_P, np) = p;
       F(JUR_F_T, np) = t;
-      if (fused) { ds_pp = ds_p; ds_p = ds; p_p = p; t_p = t; }
-      else F(JUR_F_DS, np) = ds;
+      ds_pp = ds_p; ds_p = ds;
 
       if (low_idx >= 0 && low_idx == np - 1) { TR_LZ2 = z; TR_LDS2 = ds; for (int i = 0; i < 3; i++) TR_LX2(i) = x[i]; }
       if (z < z_low) {
@@ -439,27 +436,6 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
       cart2geo(w, dummy, tplon, tplat);
     }
 
-    if (fused) {  // the last point
-      if (np > 0) {
-        double const dsn = (np >= 2) ? 0.5 * (ds_pp + ds_p) : ds_p * 0.5;
-        F(JUR_F_DS, np - 1) = dsn;
-#pragma unroll
-        for (int ig = 0; ig < QMAX; ig++)
-          if (ig < v.ng) F(f_u + ig, np - 1) = 10. * q_p[ig] * p_p / (JUR_BOLTZMANN * t_p) * dsn;
-      }
-    } else {
-      // trapezoid rule on ds (descending, jr_common.h:437-443), then column densities (:446-453)
-      for (int ip = np - 1; ip >= 0; ip--) {
-        double const dsr = F(JUR_F_DS, ip);
-        double const dsn = (ip >= 1) ? 0.5 * (F(JUR_F_DS, ip - 1) + dsr) : dsr * 0.5;
-        F(JUR_F_DS, ip) = dsn;
-        double const p = F(JUR_F_P, ip), t = F(JUR_F_T, ip);
-        for (int ig = 0; ig < v.ng; ig++) {
-          double const q = F(f_u + ig, ip);
-          F(f_u + ig, ip) = 10. * q * p / (JUR_BOLTZMANN * t) * dsn;
-        }
-      }
-    }
   }
 
   c.np[r] = np;

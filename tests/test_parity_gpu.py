@@ -143,6 +143,24 @@ def test_division_paths_return_the_same_doubles(hip, monkeypatch):
         assert np.array_equal(fast[k].view(np.uint64), ieee[k].view(np.uint64)), k
 
 
+def test_eight_emitters_with_generated_profiles(hip, oracle, tmp_path):
+    """More emitters than the examples use (column densities of all of them are written per LOS point; the
+    point before the exit has them redone when its segment is clipped), profiles from this tree's
+    `climatology` tool."""
+    import subprocess
+    emitters = ["CO2", "H2O", "O3", "F11", "CCl4", "CH4", "N2O", "HNO3"]
+    (tmp_path / "x.ctl").write_text("NG = 8\n" + "".join(f"EMITTER[{i}] = {e}\n" for i, e in enumerate(emitters))
+                                    + "ND = 2\nNU[0] = 792.0\nNU[1] = 832.0\n")
+    exe = os.path.join(common.ROOT, "jurassic-gpu_amd", "climatology")
+    assert subprocess.run([exe, "x.ctl", "atm.tab"], cwd=tmp_path, capture_output=True, timeout=60).returncode == 0
+    geom = np.vstack([synth.limb_geometry(150, seed=12), synth.nadir_geometry(40, seed=13)])
+    case = common.Case(emitters, [792.0, 832.0], str(tmp_path / "atm.tab"), geom, table_kw=dict(nlev=12, ntemp=4))
+    assert case.atm.np == 91
+    out, ref = run_both(hip, oracle, case)
+    assert_parity(out, ref)
+    assert out["rad"].min() > 0
+
+
 def test_curtis_godson_columns(hip, oracle):
     """curtis_godson (jr_common.h:455-473): per gas the running column-weighted pressure and temperature
     and the cumulative column along the path.  The device forms the along-path prefix sums with a
