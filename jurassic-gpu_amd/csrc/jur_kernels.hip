@@ -298,6 +298,8 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
 
     int stop = 0;
     for (; np < NLOS; ++np) {
+      // the bookkeeping written to LDS is to be read back from there, not kept in registers as well
+      asm volatile("" ::: "memory");
       double ds = v.rayds;
       double const dz = v.raydz;
       if (dz > 0.) {
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
       np = NLOS - 1;
     }
 
+    asm volatile("" ::: "memory");
     // tangent point from the raw segment lengths (jr_common.h:502-539)
     if (low_idx <= 0 || low_idx >= np - 1) {
       double zz;
