@@ -13,18 +13,22 @@
 //                         (jr_common.h:315-390), product over gases, Planck source (:220-224),
 //                         radiance update (:293-300); surface term, brightness temperature and
 //                         the NaN mask in the epilogue (CPUdrivers.c:5-24, jr_common.h:193-210).
-//                         Two table-search strategies in jur_ega_kernel: WARM (tables whose axes and curves
-//                         are sorted: every bracket is unique, so the search resumes from
-//                         the bracket of the previous segment -- the accumulated
-//                         transmittance only falls, the column only grows) and EXACT (the
-//                         reference's bisections probe for probe, for unsorted tables).
+//   Two table-search strategies in jur_ega_kernel: WARM (tables whose axes and curves are sorted: every
+//   bracket is unique, so the search resumes from the bracket the previous segment ended in -- the
+//   accumulated transmittance only falls, the column only grows) and EXACT (the reference's bisections
+//   probe for probe, for unsorted tables).
+//   jur_cg_kernel         optional: Curtis-Godson means along the path, one wavefront per (ray, gas)
+//                         pencil, along-path prefix sums as wavefront scans (jr_common.h:455-473).
 //   jur_raykey_kernel     geometric tangent altitude per ray; rays are then processed in
 //                         that order (hipCUB radix sort) so that the lanes of a wavefront
 //                         walk similar paths.
 //
 // All arithmetic is IEEE fp64 with the reference's operand order; tables are fp32 in memory.
 // Compiled with -ffp-contract=off so that no fused multiply-adds are formed that the
-// reference's x86-64 build does not form.
+// reference's x86-64 build does not form.  Where a division is replaced (div_rcp, div_finite,
+// div_const below) the replacement returns the same double as the division, and is checked to
+// (tools/compare_division_paths.py, tools/compare_builds.py); the one library function replaced
+// (pow with a constant base, pow_const) stays within the library's own error bound.
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
