@@ -78,11 +78,6 @@ __device__ __forceinline__ double lip_finite(double x0, double y0, double x1, do
   return y0 + div_finite((x - x0) * (y1 - y0), x1 - x0);
 }
 
-__device__ __forceinline__ double eip(double x0, double y0, double x1, double y1, double x) {
-  if ((y0 > 0) && (y1 > 0)) return y0 * exp(log(y1 / y0) / (x1 - x0) * (x - x0));
-  return lip(x0, y0, x1, y1, x);
-}
-
 // bracket search on an ascending or descending axis (jr_common.h:87-104)
 __device__ __forceinline__ int locate_axis(double const *__restrict__ xx, int n, double x) {
   int ilo = 0, ihi = n - 1, i = (n - 1) >> 1;
