@@ -175,13 +175,19 @@ def main():
         rays_per_launch = nrays * args.steps / n_launch
         avg_ms = kms["ega_ms"] / n_launch
         achieved = a_ega * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        traffic = valu_frac = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.workload)
+                pmc = json.load(open(tfile))
+                traffic = pmc.get(args.workload)
+                # what does bound the kernel: vector-ALU issue.  SQ_INSTS_VALU of one 1e6-ray launch (PMC, wavefront
+                # instructions) scaled to this launch, against 256 CUs x 4 SIMDs issuing one per 4 cycles at 2.4 GHz
+                if args.workload == "limb_1e6" and avg_ms > 0:
+                    insts = pmc["valu_insts_per_1e6_ray_launch"]["ega"] * rays_per_launch / 1e6
+                    valu_frac = insts * 4 / (avg_ms * 1e-3) / (1024 * 2.4e9)
             except Exception:
-                traffic = None
+                traffic = valu_frac = None
         out["roofline"] = {"bound": "hbm", "kernel": "jur_ega_kernel", "achieved": achieved, "peak": 8000.0,
                            "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                            "algorithmic_bytes_per_ray": a_ega, "rays_per_launch": rays_per_launch,
@@ -190,9 +196,11 @@ def main():
                            "trace_kernel_avg_ms": kms["trace_ms"] / max(1, kms["trace_launches"]),
                            "whole_path_bytes_per_ray": a_ray,
                            "whole_path_frac": a_ray * out["value"] / world / 8e12,
+                           "valu_issue_frac": valu_frac,
                            "note": "achieved prices the REFERENCE algorithm's loads (SURVEY 8d); tables are "
                                    "cache-resident and searches warm-started, so frac > 1 is possible and HBM is "
-                                   "not the physical bound -- see traffic (PMC bytes per launch) and DESIGN.md"}
+                                   "not the physical bound -- see traffic (PMC bytes per launch), valu_issue_frac (share of the "
+                                   "chip's vector-ALU issue slots the kernel uses, from PMC) and DESIGN.md"}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()          # rank 0 may still have been in its CPU-side bookkeeping
