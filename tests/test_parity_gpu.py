@@ -161,6 +161,27 @@ def test_eight_emitters_with_generated_profiles(hip, oracle, tmp_path):
     assert out["rad"].min() > 0
 
 
+def test_degenerate_sizes(hip, oracle):
+    """No emitters at all (extinction + N2/O2 continua only), a single ray with one channel and one emitter,
+    rays that all miss the atmosphere, and one ray more than a workgroup holds."""
+    geom = np.vstack([synth.limb_geometry(70, seed=3), synth.nadir_geometry(13, seed=4)])
+    case = common.Case([], [792.0, 1450.0, 2150.0], os.path.join(common.GOLD, "limb", "atm.tab"), geom)
+    np.ctypeslib.as_array(case.atm.k)[0, :case.atm.np] = 3e-4
+    out, ref = run_both(hip, oracle, case)
+    assert_parity(out, ref)
+    assert out["rad"].min() > 0
+    case = common.Case(["CO2"], [667.5], os.path.join(common.GOLD, "nadir", "atm.tab"), synth.nadir_geometry(1, seed=5),
+                       write_bbt=1)
+    out, ref = run_both(hip, oracle, case)
+    assert_parity(out, ref)
+    case = common.limb_case(geom=synth.limb_geometry(65, seed=6, zmin=200.0, zmax=400.0))
+    out, ref = run_both(hip, oracle, case)
+    assert_parity(out, ref)
+    assert out["np"].max() == 0 and out["rad"].max() == 0.0 and out["tau"].min() == 1.0
+    out, ref = run_both(hip, oracle, common.limb_case(geom=synth.limb_geometry(257, seed=7), nu=common.CTM4_NU))
+    assert_parity(out, ref)
+
+
 def test_curtis_godson_columns(hip, oracle):
     """curtis_godson (jr_common.h:455-473): per gas the running column-weighted pressure and temperature
     and the cumulative column along the path.  The device forms the along-path prefix sums with a
