@@ -40,6 +40,7 @@
 #define JUR_LEN   5000      /* max ASCII line / string length       */
 #define JUR_NLOS  400       /* max points on one line of sight      */
 #define JUR_NSHAPE 2048     /* max filter-function grid points      */
+#define JUR_NFOV  5         /* rays on either side used by the FOV convolution (jurassic.h:175) */
 #define JUR_TBLNP 40        /* max pressure levels per table        */
 #define JUR_TBLNT 30        /* max temperatures per pressure level  */
 #define JUR_TBLNU 304       /* max column densities per curve       */

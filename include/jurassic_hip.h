@@ -29,6 +29,9 @@ extern "C" {
 void formod(ctl_t const *ctl, atm_t *atm, obs_t *obs);
 void formod_GPU(ctl_t const *ctl, atm_t *atm, obs_t *obs);
 void formod_pencil(ctl_t const *ctl, atm_t *atm, obs_t *obs, int const ir);
+/* field-of-view convolution of the radiances / transmittances in obs (jurassic.h:521, jurassic.c:214-258);
+ * no-op when ctl->fov is "-"; host code */
+void formod_fov(ctl_t const *ctl, obs_t *obs);
 
 /* ---- (2) additive --------------------------------------------------------- */
 enum {
@@ -121,6 +124,13 @@ int    jur_kernel(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_
  * [nr][ng][JUR_NLOS]; entries from np[ray] on are 0.  tp (optional) and np_out (optional) as above. */
 int  jur_curtis_godson_host(jur_model_t *m, long nr, double const *const geom[7],
                             double *cgp, double *cgt, double *cgu, double *const tp[3], int *np_out);
+
+/* Field-of-view convolution on flat arrays (the arithmetic of formod_fov): time[nr], vpz[nr], rad/tau rows of
+ * nd values with row stride ld, n weights w at altitude offsets dz (jur_fov_read_shape reads the
+ * two-column file ctl->fov names, at most JUR_NSHAPE rows).  In place; host code. */
+int  jur_fov_read_shape(char const *filename, int *n, double *dz, double *w);
+int  jur_fov_apply(int nd, long nr, double const *time, double const *vpz, double *rad, double *tau, long ld,
+                   int n, double const *dz, double const *w);
 
 /* Allocate the workspace for calls of up to nr rays now.  jur_formod_device allocates lazily on
  * first use; after jur_model_reserve (or one call of the same size) it only enqueues kernels on

@@ -12,6 +12,7 @@ import os
 ND = int(os.environ.get("JUR_ND", "100"))
 NG = int(os.environ.get("JUR_NG", "30"))
 NP, NR, NW, LEN, NLOS = 9600, 1088, 1, 5000, 400
+NSHAPE, NFOV = 2048, 5
 TBLNP, TBLNT, TBLNU, TBLNS = 40, 30, 304, 1201
 
 d = C.c_double

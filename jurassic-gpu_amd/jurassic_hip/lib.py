@@ -27,6 +27,10 @@ def lib():
                                 "or __graft_entry__.build(); no CPU fallback exists")
         L = C.CDLL(SO)
         L.jur_last_error.restype = C.c_char_p
+        L.jur_fov_read_shape.argtypes = [C.c_char_p, C.POINTER(C.c_int), dp, dp]
+        L.jur_fov_apply.argtypes = [C.c_int, C.c_long, dp, dp, dp, dp, C.c_long, C.c_int, dp, dp]
+        L.formod_fov.argtypes = [C.c_void_p, C.c_void_p]
+        L.formod_fov.restype = None
         L.jur_tables_new.restype = C.c_void_p
         L.jur_tables_new.argtypes = [C.c_int, C.c_int]
         L.jur_tables_free.argtypes = [C.c_void_p]
@@ -220,6 +224,26 @@ class Model:
 def formod(ctl, atm, obs):
     """Drop-in entry (reference CPUdrivers.c:179): tables from ctl.tblbase files."""
     lib().formod(C.byref(ctl), C.byref(atm), C.byref(obs))
+
+
+def formod_fov(ctl, obs):
+    """Drop-in field-of-view convolution (reference jurassic.c:214): shape file named by ctl.fov."""
+    lib().formod_fov(C.byref(ctl), C.byref(obs))
+
+
+def fov_read_shape(path):
+    dz, w = np.zeros(abi.NSHAPE), np.zeros(abi.NSHAPE)
+    n = C.c_int(0)
+    _chk(lib().jur_fov_read_shape(path.encode(), C.byref(n), _p(dz), _p(w)))
+    return dz[:n.value].copy(), w[:n.value].copy()
+
+
+def fov_apply(time, vpz, rad, tau, dz, w):
+    """Field-of-view convolution on flat arrays, in place: rad/tau (nr, nd) C-contiguous float64."""
+    time, vpz, dz, w = (np.ascontiguousarray(a, dtype=np.float64) for a in (time, vpz, dz, w))
+    assert rad.flags.c_contiguous and tau.flags.c_contiguous and rad.dtype == np.float64 and rad.shape == tau.shape
+    nr, nd = rad.shape
+    _chk(lib().jur_fov_apply(nd, nr, _p(time), _p(vpz), _p(rad), _p(tau), nd, len(dz), _p(dz), _p(w)))
 
 
 def formod_pencil(ctl, atm, obs, ir):

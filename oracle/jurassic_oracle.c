@@ -962,3 +962,50 @@ int orc_curtis_godson(ctl_t const *ctl, atm_t const *atm, double const geom[7], 
   free(los);
   return np;
 }
+
+/* ---- field-of-view convolution: formod_fov, src/jurassic.c:214-258 (shape already read: read_shape
+ *      :1134-1150 is two columns, altitude offset and weight) -------------------------------------- */
+#define LIN(x0, y0, x1, y1, x) ((y0) + ((x) - (x0)) * ((y1) - (y0)) / ((x1) - (x0)))   /* jurassic.h:81 */
+int orc_formod_fov(ctl_t const *ctl, obs_t *obs, int n, double const *dz, double const *w) {
+  enum { NFOV = 5 };                                    /* jurassic.h:175 */
+  obs_t *obs2 = (obs_t *)malloc(sizeof(obs_t));
+  if (!obs2) return -3;
+  memcpy(obs2, obs, sizeof(obs_t));                     /* copy_obs(ctl, &obs2, obs, 0) */
+  double (*rad)[JUR_ND] = malloc(sizeof(double) * (2 * NFOV + 1) * JUR_ND), (*tau)[JUR_ND] = malloc(sizeof(double) * (2 * NFOV + 1) * JUR_ND);
+  if (!rad || !tau) { free(rad); free(tau); free(obs2); return -3; }
+  double z[2 * NFOV + 1];
+  for (int ir = 0; ir < obs->nr; ir++) {
+    int nz = 0;
+    int const first = ir - NFOV > 0 ? ir - NFOV : 0, last = ir + 1 + NFOV < obs->nr ? ir + 1 + NFOV : obs->nr;
+    for (int ir2 = first; ir2 < last; ir2++)
+      if (obs->time[ir2] == obs->time[ir]) {
+        z[nz] = obs2->vpz[ir2];
+        for (int id = 0; id < ctl->nd; id++) {
+          rad[nz][id] = obs2->rad[ir2][id];
+          tau[nz][id] = obs2->tau[ir2][id];
+        }
+        nz++;
+      }
+    if (nz < 2) { free(obs2); free(rad); free(tau); return -1; }   /* ERRMSG("Cannot apply FOV convolution!") */
+    double wsum = 0;
+    for (int id = 0; id < ctl->nd; id++) {
+      obs->rad[ir][id] = 0;
+      obs->tau[ir][id] = 0;
+    }
+    for (int i = 0; i < n; i++) {
+      double const zfov = obs->vpz[ir] + dz[i];
+      int const idx = locate(z, nz, zfov);
+      for (int id = 0; id < ctl->nd; id++) {
+        obs->rad[ir][id] += w[i] * LIN(z[idx], rad[idx][id], z[idx + 1], rad[idx + 1][id], zfov);
+        obs->tau[ir][id] += w[i] * LIN(z[idx], tau[idx][id], z[idx + 1], tau[idx + 1][id], zfov);
+      }
+      wsum += w[i];
+    }
+    for (int id = 0; id < ctl->nd; id++) {
+      obs->rad[ir][id] /= wsum;
+      obs->tau[ir][id] /= wsum;
+    }
+  }
+  free(obs2); free(rad); free(tau);
+  return 0;
+}

@@ -40,6 +40,7 @@ def lib():
         L.orc_tbl_feed_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, dp, dp, dp, dp]
         L.orc_tbl_planck_shape.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp]
         L.orc_formod.argtypes = [C.c_void_p] * 4
+        L.orc_formod_fov.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp]
         L.orc_formod_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int] + [dp] * 12 + \
             [C.POINTER(C.c_int), dp, C.c_int]
         L.orc_algorithmic_bytes.restype = C.c_double
@@ -157,6 +158,14 @@ def kernel(ctl, atm, obs, tables):
     k = np.zeros((m, n))
     lib().orc_kernel(C.byref(ctl), C.byref(atm), C.byref(obs), tables.h, _p(k), m, n)
     return k
+
+
+def formod_fov(ctl, obs, dz, w):
+    """formod_fov (jurassic.c:214-258) on obs in place, with the shape already read; -> 0 or -1 (fewer than
+    two rays share a time stamp: the reference aborts)."""
+    dz = np.ascontiguousarray(dz, dtype=np.float64)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    return lib().orc_formod_fov(C.byref(ctl), C.byref(obs), len(dz), _p(dz), _p(w))
 
 
 def curtis_godson(ctl, atm, geom7):

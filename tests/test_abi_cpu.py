@@ -160,6 +160,67 @@ def test_climatology_random_profiles_and_checkmode(tmp_path):
     assert run("none.tab", "CHECKMODE", "1").returncode == 0 and not (tmp_path / "none.tab").exists()
 
 
+def _fov_obs(nd=3, scans=3, per_scan=30, descending=False, seed=0):
+    """obs_t with `scans` limb scans (one time stamp each) and smooth synthetic radiance / transmittance profiles."""
+    rng = np.random.default_rng(seed)
+    obs = abi.obs_t()
+    obs.nr = scans * per_scan
+    z = np.linspace(5.0, 63.0, per_scan)
+    if descending:
+        z = z[::-1]
+    for s_ in range(scans):
+        for i in range(per_scan):
+            ir = s_ * per_scan + i
+            obs.time[ir] = float(s_)
+            obs.vpz[ir] = z[i] + 0.01 * s_
+            for d in range(nd):
+                obs.rad[ir][d] = np.exp(-z[i] / (7.0 + d)) * (1 + 0.1 * rng.random())
+                obs.tau[ir][d] = 1 - 0.9 * np.exp(-z[i] / (9.0 + d))
+    return obs
+
+
+@pytest.mark.parametrize("descending", [False, True])
+def test_fov_convolution_matches_the_restatement(oracle, tmp_path, descending):
+    """formod_fov (jurassic.c:214-258): library and oracle restatement agree bit for bit; flat-array entry
+    equals the obs_t entry; FOV = '-' is a no-op; a linear profile is a fixed point of a symmetric FOV."""
+    import copy
+    nd = 3
+    ctl = abi.make_ctl(["CO2"], [700.0, 800.0, 900.0])
+    dz = np.linspace(-1.5, 1.5, 21)
+    w = np.exp(-0.5 * (dz / 0.6) ** 2)
+    shape = tmp_path / "fov.shape"
+    shape.write_text("# dz [km]  weight\n" + "".join(f"{a:.6f} {b:.8g}\n" for a, b in zip(dz, w)))
+    rdz, rw = lib.fov_read_shape(str(shape))
+    assert len(rdz) == 21
+    a, b = _fov_obs(nd, descending=descending), _fov_obs(nd, descending=descending)
+    rad_in = np.ctypeslib.as_array(a.rad)[:a.nr, :nd].copy()
+    tau_in = np.ctypeslib.as_array(a.tau)[:a.nr, :nd].copy()
+    lib.formod_fov(ctl, a)                                     # ctl.fov == "-": nothing happens
+    assert np.array_equal(np.ctypeslib.as_array(a.rad)[:a.nr, :nd], rad_in)
+    ctl.fov = str(shape).encode()
+    lib.formod_fov(ctl, a)
+    assert oracle.formod_fov(ctl, b, rdz, rw) == 0
+    for name in ("rad", "tau"):
+        x, y = np.ctypeslib.as_array(getattr(a, name))[:a.nr, :nd], np.ctypeslib.as_array(getattr(b, name))[:a.nr, :nd]
+        assert np.array_equal(x.view(np.uint64), y.view(np.uint64)), name
+    assert not np.array_equal(np.ctypeslib.as_array(a.rad)[:a.nr, :nd], rad_in)
+    time = np.ctypeslib.as_array(a.time)[:a.nr].copy()
+    vpz = np.ctypeslib.as_array(a.vpz)[:a.nr].copy()
+    r2, t2 = rad_in.copy(), tau_in.copy()
+    lib.fov_apply(time, vpz, r2, t2, rdz, rw)
+    assert np.array_equal(r2, np.ctypeslib.as_array(a.rad)[:a.nr, :nd])
+    lin = np.repeat((2.0 + 0.3 * vpz)[:, None], nd, axis=1).copy()        # linear in z: unchanged away from scan ends
+    lin2, dummy = lin.copy(), lin.copy()
+    lib.fov_apply(time, vpz, lin2, dummy, rdz, rw)
+    inner = np.concatenate([np.arange(s_ * 30 + 2, s_ * 30 + 28) for s_ in range(3)])
+    assert np.allclose(lin2[inner], lin[inner], rtol=1e-12)
+    lone = _fov_obs(nd, scans=1, per_scan=1)                                # a ray alone in its scan: upstream aborts
+    assert oracle.formod_fov(ctl, lone, rdz, rw) == -1
+    one_r, one_t = np.ones((1, nd)), np.ones((1, nd))
+    with pytest.raises(lib.JurassicError, match="Cannot apply FOV"):
+        lib.fov_apply(np.zeros(1), np.array([10.0]), one_r, one_t, rdz, rw)
+
+
 def test_compute_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
