@@ -78,3 +78,17 @@ def rel_err(a, b):
     a, b = np.asarray(a), np.asarray(b)
     den = np.maximum(np.abs(b), 1e-300)
     return np.abs(a - b) / den
+
+
+def oracle_goldens():
+    """Committed oracle results for the reference examples with the seeded synthetic tables
+    (tests/golden/oracle_examples.json, written by tools/make_oracle_goldens.py): name -> (case, dict of arrays)."""
+    import json
+    doc = json.load(open(os.path.join(GOLD, "oracle_examples.json")))
+    cases = {"limb": limb_case(), "nadir": nadir_case(), "limb_four_continua": limb_case(nu=CTM4_NU)}
+    out = {}
+    for name, g in doc["cases"].items():
+        arr = {k: np.array([[float.fromhex(v) for v in row] for row in g[k]]) for k in ("rad", "tau", "tp")}
+        arr["np"] = np.array(g["np"], dtype=np.int32)
+        out[name] = (cases[name], arr)
+    return out

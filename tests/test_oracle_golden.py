@@ -171,3 +171,14 @@ def test_oracle_jacobian_is_consistent_with_two_forward_runs(oracle):
     q[1, 5] = q0
     assert np.allclose(K[:, 3], col, rtol=1e-12, atol=0)
     assert np.all(K[:, :3].max(axis=0) > 0)               # warmer air radiates more
+
+
+def test_oracle_reproduces_its_committed_example_results(oracle):
+    """tests/golden/oracle_examples.json pins the oracle itself (not reference-produced: DESIGN.md section 2).
+    1e-13 relative leaves room for a libm that rounds exp/pow/tanh differently; point counts are exact."""
+    for name, (case, gold) in common.oracle_goldens().items():
+        ref = oracle.formod_rays(case.ctl, case.atm, case.oracle_tables(oracle), case.geom)
+        assert np.array_equal(ref["np"], gold["np"]), name
+        for k in ("rad", "tau"):
+            assert np.max(common.rel_err(ref[k], gold[k])) < 1e-13, (name, k)
+        assert np.max(np.abs(ref["tp"] - gold["tp"])) < 1e-11, name

@@ -182,6 +182,17 @@ def test_degenerate_sizes(hip, oracle):
     assert_parity(out, ref)
 
 
+def test_against_committed_example_results(hip):
+    """HIP path against tests/golden/oracle_examples.json (no oracle run involved): the two reference examples
+    and the four-continua limb case with the seeded synthetic tables."""
+    for name, (case, gold) in common.oracle_goldens().items():
+        model = hip.Model(case.ctl, case.lib_tables())
+        model.set_atm(case.atm)
+        out = model.formod_host(case.geom)
+        model.close()
+        assert_parity(out, gold)
+
+
 def test_curtis_godson_columns(hip, oracle):
     """curtis_godson (jr_common.h:455-473): per gas the running column-weighted pressure and temperature
     and the cumulative column along the path.  The device forms the along-path prefix sums with a
