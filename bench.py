@@ -57,9 +57,17 @@ def cpu_baseline(case, target_s=15.0):
     dt = time.perf_counter() - t0
     nb = min(len(case.geom), 4096)
     ab = orc.algorithmic_bytes(case.ctl, case.atm, ot, case.geom[:nb])
+    # one thread, the reference's own arrangement (ray tracing outside the parallel region), one package
+    threads = orc.set_threads(1)
+    n2 = min(len(case.geom), 1088)
+    t0 = time.perf_counter()
+    orc.formod_rays(case.ctl, case.atm, ot, case.geom[:n2], serial_trace=True)
+    dt1 = time.perf_counter() - t0
+    orc.set_threads(threads)
     return dict(value=n1 / dt, unit="rays/s", cores=cores, kind="port",
                 sample="first %d rays of the workload in packages of 1088, OpenMP over rays incl. tracing, %.1f s"
-                       % (n1, dt)), ab
+                       % (n1, dt),
+                one_thread_value=n2 / dt1, one_thread_sample="first %d rays, 1 thread, %.1f s" % (n2, dt1)), ab
 
 
 def main():

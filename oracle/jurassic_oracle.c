@@ -13,6 +13,9 @@
 #include <string.h>
 #include <strings.h>
 #include <assert.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "jurassic_oracle.h"
 
 #define NLOS JUR_NLOS
@@ -1009,3 +1012,15 @@ int orc_formod_fov(ctl_t const *ctl, obs_t *obs, int n, double const *dz, double
   free(obs2); free(rad); free(tau);
   return 0;
 }
+
+/* number of OpenMP threads the next calls use (0: leave as is); returns the current maximum */
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+

@@ -115,6 +115,7 @@ int orc_traceray(ctl_t const *ctl, atm_t const *atm, double const geom[7],
                  double *tsurf, double tp[3]);
 void orc_hydrostatic(ctl_t const *ctl, atm_t *atm);
 /* Curtis-Godson means of one ray (jr_common.h:455-473): cgp/cgt/cgu are [JUR_NG... ng][JUR_NLOS]; returns np */
+int orc_set_threads(int n);
 int orc_formod_fov(ctl_t const *ctl, obs_t *obs, int n, double const *dz, double const *w);
 int orc_curtis_godson(ctl_t const *ctl, atm_t const *atm, double const geom[7], double *cgp, double *cgt, double *cgu);
 int  orc_find_emitter(ctl_t const *ctl, char const *name);

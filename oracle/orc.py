@@ -160,6 +160,11 @@ def kernel(ctl, atm, obs, tables):
     return k
 
 
+def set_threads(n=0):
+    """OpenMP threads of the following calls (0: unchanged) -> current maximum."""
+    return lib().orc_set_threads(int(n))
+
+
 def formod_fov(ctl, obs, dz, w):
     """formod_fov (jurassic.c:214-258) on obs in place, with the shape already read; -> 0 or -1 (fewer than
     two rays share a time stamp: the reference aborts)."""
