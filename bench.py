@@ -37,37 +37,59 @@ def build_case(workload, nrays, seed):
     return case
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a box may show all
+    host threads in the mask and still be limited to a share of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                   # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                   # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(case, target_s=15.0):
-    """Oracle (CPU restatement of CPUdrivers.c) timed on a bounded sample of the
-    same workload, all host cores.  A reported baseline, not the target."""
+    """Oracle (CPU restatement of CPUdrivers.c) timed on bounded samples of the same workload.
+    value: all host cores, every thread tracing and integrating its own rays (the fair many-core arrangement);
+    as_reference_value: the reference's arrangement, packages of 1088 rays with OpenMP inside each;
+    one_thread_value: one package on one thread.  A reported baseline, not the target."""
     from oracle import orc
     orc.build()
     ot = case.oracle_tables(orc)
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    n0 = min(len(case.geom), 2048)
-    t0 = time.perf_counter()
-    orc.formod_rays(case.ctl, case.atm, ot, case.geom[:n0])
-    dt = time.perf_counter() - t0
+    cores = usable_cores()
+    orc.set_threads(cores)
+
+    def timed(n, mode):
+        t0 = time.perf_counter()
+        orc.formod_rays(case.ctl, case.atm, ot, case.geom[:n], serial_trace=mode)
+        return time.perf_counter() - t0
+
+    n0 = min(len(case.geom), 16384)
+    dt = timed(n0, 2)
     n1 = int(min(len(case.geom), max(n0, n0 * target_s / max(dt, 1e-3))))
-    n1 = max(1088, n1 // 1088 * 1088)
-    n1 = min(n1, len(case.geom))
-    t0 = time.perf_counter()
-    orc.formod_rays(case.ctl, case.atm, ot, case.geom[:n1])
-    dt = time.perf_counter() - t0
-    nb = min(len(case.geom), 4096)
-    ab = orc.algorithmic_bytes(case.ctl, case.atm, ot, case.geom[:nb])
-    # one thread, the reference's own arrangement (ray tracing outside the parallel region), one package
+    dt = timed(n1, 2)
+    na = min(len(case.geom), 8 * 1088)
+    dta = timed(na, 0)
     threads = orc.set_threads(1)
     n2 = min(len(case.geom), 1088)
-    t0 = time.perf_counter()
-    orc.formod_rays(case.ctl, case.atm, ot, case.geom[:n2], serial_trace=True)
-    dt1 = time.perf_counter() - t0
+    dt1 = timed(n2, 1)
     orc.set_threads(threads)
+    nb = min(len(case.geom), 4096)
+    ab = orc.algorithmic_bytes(case.ctl, case.atm, ot, case.geom[:nb])
     return dict(value=n1 / dt, unit="rays/s", cores=cores, kind="port",
-                sample="first %d rays of the workload in packages of 1088, OpenMP over rays incl. tracing, %.1f s"
+                sample="first %d rays of the workload, OpenMP over rays (each thread traces and integrates its own), %.1f s"
                        % (n1, dt),
-                one_thread_value=n2 / dt1, one_thread_sample="first %d rays, 1 thread, %.1f s" % (n2, dt1)), ab
+                as_reference_value=na / dta,
+                as_reference_sample="first %d rays in packages of 1088, OpenMP inside each package, %.1f s" % (na, dta),
+                one_thread_value=n2 / dt1, one_thread_sample="first %d rays, 1 thread, serial tracing, %.1f s" % (n2, dt1)), ab
 
 
 def main():

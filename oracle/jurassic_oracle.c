@@ -751,6 +751,31 @@ void orc_formod_rays(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tb, long nr,
   continua_config(ctl, &ig_co2, &ig_h2o, &fourbit);
   if (!(ctl->hydz < 0)) hydrostatic_1d_h2o(ctl, atm, 0, atm->np, ig_h2o);
 
+  if (serial_trace == 2) {  /* "rays-parallel": every thread traces and integrates its own rays, one LOS buffer per
+                             * thread -- the fair many-core arrangement, same results per ray */
+#pragma omp parallel
+    {
+      pos_t *los1 = (pos_t *)malloc(sizeof(pos_t) * NLOS);
+#pragma omp for schedule(dynamic, 8)
+      for (long ir = 0; ir < nr; ir++) {
+        char mask1[JUR_ND];
+        for (int id = 0; id < ctl->nd; id++) mask1[id] = !isfinite(rad[ir * nd_stride + id]);
+        double const geom[7] = {time[ir], obsz[ir], obslon[ir], obslat[ir], vpz[ir], vplon[ir], vplat[ir]};
+        double tp[3], ts;
+        int const n1 = traceray(ctl, atm, geom, los1, &ts, tp);
+        tpz[ir] = tp[0]; tplon[ir] = tp[1]; tplat[ir] = tp[2];
+        integrate_ray(ctl, tb, los1, n1, ts, ig_co2, ig_h2o, fourbit, rad + ir * nd_stride, tau + ir * nd_stride, nd_stride);
+        if (ctl->write_bbt)
+          for (int id = 0; id < ctl->nd; id++) rad[ir * nd_stride + id] = orc_brightness(rad[ir * nd_stride + id], ctl->nu[id]);
+        for (int id = 0; id < ctl->nd; id++)
+          if (mask1[id]) rad[ir * nd_stride + id] = NAN;
+        if (np_out) np_out[ir] = n1;
+        if (tsurf_out) tsurf_out[ir] = ts;
+      }
+      free(los1);
+    }
+    return;
+  }
   long const chunk = JUR_NR;                            /* the reference works in packages of NR rays */
   pos_t *los = (pos_t *)malloc(sizeof(pos_t) * NLOS * (size_t)chunk);
   int *np = (int *)malloc(sizeof(int) * chunk);
@@ -760,7 +785,7 @@ void orc_formod_rays(ctl_t const *ctl, atm_t *atm, orc_tbl_t const *tb, long nr,
     long const n = (nr - r0 < chunk) ? nr - r0 : chunk;
     for (long i = 0; i < n; i++)                        /* save_mask, jr_common.h:193-200 */
       for (int id = 0; id < ctl->nd; id++) mask[i * ctl->nd + id] = !isfinite(rad[(r0 + i) * nd_stride + id]);
-#pragma omp parallel for schedule(dynamic, 4) if (!serial_trace)
+#pragma omp parallel for schedule(dynamic, 4) if (serial_trace != 1)
     for (long i = 0; i < n; i++) {                      /* raytrace_rays_CPU */
       long const ir = r0 + i;
       double const geom[7] = {time[ir], obsz[ir], obslon[ir], obslat[ir], vpz[ir], vplon[ir], vplat[ir]};

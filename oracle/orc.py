@@ -106,7 +106,9 @@ def formod(ctl, atm, obs, tables):
 
 def formod_rays(ctl, atm, tables, geom, rad_in=None, serial_trace=False):
     """geom: (nr, 7) array [time, obsz, obslon, obslat, vpz, vplon, vplat].
-    -> dict(rad, tau, tp (nr,3), np, tsurf)."""
+    -> dict(rad, tau, tp (nr,3), np, tsurf).
+    serial_trace: False/0 packages of 1088 rays with OpenMP inside each (tracing too), True/1 the reference's
+    arrangement (tracing serial), 2 every thread traces and integrates its own rays (no packages)."""
     g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
     nr, nd = g.shape[1], ctl.nd
     rad = np.zeros((nr, nd)) if rad_in is None else np.ascontiguousarray(rad_in, dtype=np.float64).copy()
