@@ -38,6 +38,8 @@ out = {"what": "forward-difference Jacobian, limb example", "rows": K.shape[0], 
        "gpu_s": t_gpu, "gpu_columns_per_s": K.shape[1] / t_gpu}
 if "--no-cpu" not in sys.argv:
     orc.build()
+    import bench
+    orc.set_threads(bench.usable_cores())   # the cores the box grants (cgroup quota), not the affinity mask
     tb = case.oracle_tables(orc)
     t0 = time.perf_counter()
     K_ref = orc.kernel(c, case.atm, obs_of(case.geom), tb)
@@ -53,7 +55,7 @@ if "--no-cpu" not in sys.argv:
                         np.maximum(np.abs(0.01 * x0[2 * n0:(2 + c.ng) * n0]), 1e-15), np.full(n0, 1e-4)])
     y = np.ctypeslib.as_array(obs.rad)[:obs.nr, :c.nd].ravel()
     tol = 1e-6 * np.abs(K_ref).max(axis=0)[None, :] + 1e-12 * np.abs(y)[:, None] / h[None, :]
-    out.update(cpu_s=t_cpu, cpu_columns_per_s=K.shape[1] / t_cpu, cpu_threads=len(os.sched_getaffinity(0)),
+    out.update(cpu_s=t_cpu, cpu_columns_per_s=K.shape[1] / t_cpu, cpu_threads=bench.usable_cores(),
                max_dev_over_tolerance=float(np.max(np.abs(K - K_ref) / tol)),
                tolerance="1e-6 * max|K[:, j]| + 1e-12 * |y_i| / h_j")
 print(json.dumps(out))
