@@ -26,4 +26,6 @@ def pytest_sessionstart(session):
 def oracle():
     from oracle import orc
     orc.build()
+    import bench
+    orc.set_threads(bench.usable_cores())      # the affinity mask may show more threads than the cgroup quota grants
     return orc
