@@ -198,6 +198,7 @@ def main():
         if ab is None:
             from oracle import orc
             orc.build()
+            orc.set_threads(usable_cores())
             ab = orc.algorithmic_bytes(case.ctl, case.atm, case.oracle_tables(orc), case.geom[:4096])
         a_ega = ab["ega"] / ab["rays"]                # algorithmic bytes per ray priced on the dominant kernel
         a_ray = ab["total"] / ab["rays"]
