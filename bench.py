@@ -101,6 +101,11 @@ def main():
     ap.add_argument("--rays", type=int, default=0, help="rays per GPU (default: the workload's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    # stdout carries exactly one JSON line: whatever libraries print to file descriptor 1 on the way (RCCL's
+    # version banner, for one) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -232,7 +237,8 @@ def main():
                                    "cache-resident and searches warm-started, so frac > 1 is possible and HBM is "
                                    "not the physical bound -- see traffic (PMC bytes per launch), valu_issue_frac (share of the "
                                    "chip's vector-ALU issue slots the kernel uses, from PMC) and DESIGN.md"}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()          # rank 0 may still have been in its CPU-side bookkeeping
         dist.destroy_process_group()
