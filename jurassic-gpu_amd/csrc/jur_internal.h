@@ -144,6 +144,7 @@ void jur_flat_free(jur_flat_t *f);
 void jur_tables_cache_filename(char *out, size_t len, ctl_t const *ctl);
 int jur_chan_setup(jur_chan_t *ch, double nu, int window);
 void jur_set_error(char const *fmt, ...);
+int  jur_parse_number(char const **pp, double *out);   /* strtod-equivalent reader of the table files */
 
 extern const double jur_ctm_blob[] __attribute__((visibility("hidden")));
 

@@ -14,6 +14,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+#include <unistd.h>
 #include "jur_internal.h"
 
 /* ---- error text ----------------------------------------------------------- */
@@ -156,7 +158,7 @@ typedef struct {
   int ip, it, iu, cap_lv;
 } feeder_t;
 
-static int feed_one(jur_tables_t *tb, jur_pair_t *pr, feeder_t *f, double press, double temp, double u, double eps) {
+static int feed_one(long *ignored_rows, jur_pair_t *pr, feeder_t *f, double press, double temp, double u, double eps) {
   if (press != f->press_old) {
     f->press_old = press;
     if (++f->ip >= JUR_TBLNP) { jur_set_error("too many pressure levels (max %d)", JUR_TBLNP); return JUR_EINVAL; }
@@ -189,7 +191,7 @@ static int feed_one(jur_tables_t *tb, jur_pair_t *pr, feeder_t *f, double press,
     f->eps_old = eps;
     f->u_old = u;
     if (++f->iu >= JUR_TBLNU) {
-      tb->ignored_rows++;
+      (*ignored_rows)++;
       f->iu--;
       return JUR_OK;
     }
@@ -225,40 +227,187 @@ int jur_tables_feed_rows(jur_tables_t *tb, int ig, int id, long nrows, double co
   feeder_t f;
   feeder_init(&f);
   for (long i = 0; i < nrows; i++) {
-    int const rc = feed_one(tb, pr, &f, p[i], t[i], u[i], eps[i]);
+    int const rc = feed_one(&tb->ignored_rows, pr, &f, p[i], t[i], u[i], eps[i]);
     if (rc) return rc;
   }
   return JUR_OK;
 }
 
-int jur_tables_read_ascii(jur_tables_t *tb, ctl_t const *ctl) {
-  if (!tb || tb->ng < ctl->ng || tb->nd < ctl->nd) { jur_set_error("read_ascii: tables smaller than ctl"); return JUR_EINVAL; }
+/* One decimal number from *pp, as strtod reads it.  Numbers of up to 15 significant digits whose decimal
+ * exponent stays within +-22 -- everything a table written with %g or %.9g holds -- are formed as
+ * (integer < 2^53) * or / (exact power of ten): one correctly rounded operation, the same double strtod
+ * returns (Clinger's fast path).  Anything else (more digits, large exponents, inf/nan, hex floats, a token that
+ * does not end at white space) goes to strtod.  glibc's strtod does not scale over threads here (8 threads:
+ * the throughput of one), and it is the whole cost of reading a table file.  Returns 1 and advances *pp on
+ * success, 0 if no number starts there. */
+int jur_parse_number(char const **pp, double *out) {
+  static double const p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  char const *p = *pp;
+  while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\v' || *p == '\f') p++;
+  char const *const start = p;
+  int neg = 0;
+  if (*p == '-') { neg = 1; p++; } else if (*p == '+') p++;
+  unsigned long long m = 0;
+  int sig = 0, dexp = 0, any = 0, simple = 1;
+  for (; *p >= '0' && *p <= '9'; p++) {
+    any = 1;
+    if (sig < 15) { m = m * 10 + (unsigned)(*p - '0'); if (m) sig++; }
+    else { simple = 0; dexp++; }
+  }
+  if (*p == '.') {
+    p++;
+    for (; *p >= '0' && *p <= '9'; p++) {
+      any = 1;
+      if (sig < 15) { m = m * 10 + (unsigned)(*p - '0'); if (m) sig++; dexp--; }
+      else simple = 0;
+    }
+  }
+  if (any && (*p == 'e' || *p == 'E')) {
+    char const *q = p + 1;
+    int eneg = 0, e = 0, edig = 0;
+    if (*q == '-') { eneg = 1; q++; } else if (*q == '+') q++;
+    for (; *q >= '0' && *q <= '9'; q++) { if (e < 10000) e = e * 10 + (*q - '0'); edig = 1; }
+    if (edig) { dexp += eneg ? -e : e; p = q; }
+  }
+  int const ends = (*p == '\0' || *p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\v' || *p == '\f');
+  if (any && simple && ends && dexp >= -22 && dexp <= 22) {
+    double v = (double)m;                                /* exact: m < 10^15 < 2^53 */
+    v = dexp < 0 ? v / p10[-dexp] : v * p10[dexp];
+    *out = neg ? -v : v;
+    *pp = p;
+    return 1;
+  }
+  char *end;
+  double const v = strtod(start, &end);
+  if (end == start) return 0;
+  *out = v;
+  *pp = end;
+  return 1;
+}
+
+/* Host threads worth starting for file work: online CPUs capped by the cgroup CPU quota and by 32
+ * (JUR_IO_THREADS overrides). */
+static int io_threads(void) {
+  char const *e = getenv("JUR_IO_THREADS");
+  if (e && atoi(e) > 0) return atoi(e);
+  long n = sysconf(_SC_NPROCESSORS_ONLN);
+  FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f) {
+    char q[64];
+    long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      long const c = (atol(q) + period - 1) / period;
+      if (c >= 1 && c < n) n = c;
+    }
+    fclose(f);
+  }
+  if (n < 1) n = 1;
+  return n > 32 ? 32 : (int)n;
+}
+
+/* One table file per (emitter, channel) pair, jurassic.c:329-400; the files are independent, so they are
+ * parsed by a few threads (upstream reads them one after the other: 1.2 s for the 10 files of the example,
+ * minutes for thousands of channels). */
+typedef struct {
+  jur_tables_t *tb;
+  ctl_t const *ctl;
+  int next, found, rc;
+  long ignored;
+  char err[512];
+  pthread_mutex_t mu;
+} ascii_job_t;
+
+static void *ascii_worker(void *arg) {
+  ascii_job_t *job = (ascii_job_t *)arg;
+  ctl_t const *ctl = job->ctl;
+  jur_tables_t *tb = job->tb;
+  char *filename = (char *)malloc(2 * JUR_LEN + 64);
+  long ignored = 0;
   int found = 0;
-  char *line = (char *)malloc(JUR_LEN);
-  for (int ig = 0; ig < ctl->ng; ig++)
-    for (int id = 0; id < ctl->nd; id++) {
-      char filename[2 * JUR_LEN + 64];
-      snprintf(filename, sizeof filename, "%s_%.4f_%s.tab", ctl->tblbase, ctl->nu[id], ctl->emitter[ig]);
-      FILE *in = fopen(filename, "r");
-      if (!in) continue;                                /* transparent gas for this channel */
-      found++;
+  for (;;) {
+    pthread_mutex_lock(&job->mu);
+    int const k = (job->rc == JUR_OK) ? job->next++ : ctl->ng * ctl->nd;
+    pthread_mutex_unlock(&job->mu);
+    if (k >= ctl->ng * ctl->nd || !filename) break;
+    int const ig = k / ctl->nd, id = k % ctl->nd;
+    snprintf(filename, 2 * JUR_LEN + 64, "%s_%.4f_%s.tab", ctl->tblbase, ctl->nu[id], ctl->emitter[ig]);
+    FILE *in = fopen(filename, "r");
+    if (!in) continue;                                  /* transparent gas for this channel */
+    found++;
+    /* the whole file in one buffer (few large reads), lines cut in place */
+    size_t cap = 1 << 22, len = 0;
+    char *buf = (char *)malloc(cap + 1);
+    while (buf) {
+      size_t const got = fread(buf + len, 1, cap - len, in);
+      len += got;
+      if (len < cap) break;
+      cap *= 2;
+      char *nb = (char *)realloc(buf, cap + 1);
+      if (!nb) { free(buf); buf = NULL; }
+      else buf = nb;
+    }
+    fclose(in);
+    int rc = JUR_OK;
+    if (!buf) { jur_set_error("out of memory reading table file"); rc = JUR_ENOMEM; }
+    else {
+      buf[len] = '\0';
       jur_pair_t *pr = &tb->pair[(size_t)ig * tb->nd + id];
       pair_clear(pr);
       feeder_t f;
       feeder_init(&f);
-      while (fgets(line, JUR_LEN, in)) {
+      for (char *l = buf; !rc && l < buf + len;) {
+        char *const nl = (char *)memchr(l, '\n', (size_t)(buf + len - l));
+        char *const next = nl ? nl + 1 : buf + len;
+        /* upstream reads with fgets(line, LEN): a longer line continues as a new line */
+        char *const stop = (next - l > JUR_LEN - 1) ? l + (JUR_LEN - 1) : next;
+        char const saved = *stop;
+        *stop = '\0';
         double eps = 0, press = 0, temp = 0, u = 0;
-        if (sscanf(line, "%lg %lg %lg %lg", &press, &temp, &u, &eps) != 4) continue;
-        int const rc = feed_one(tb, pr, &f, press, temp, u, eps);
-        if (rc) { fclose(in); free(line); return rc; }
+        char const *q = l;                               /* four numbers, as sscanf("%lg %lg %lg %lg") accepts them */
+        if (jur_parse_number(&q, &press) && jur_parse_number(&q, &temp) && jur_parse_number(&q, &u) &&
+            jur_parse_number(&q, &eps))
+          rc = feed_one(&ignored, pr, &f, press, temp, u, eps);
+        *stop = saved;
+        l = stop;
       }
-      fclose(in);
+      free(buf);
     }
-  free(line);
+    if (rc) {
+      pthread_mutex_lock(&job->mu);
+      if (job->rc == JUR_OK) { job->rc = rc; snprintf(job->err, sizeof job->err, "%s: %s", filename, jur_last_error()); }
+      pthread_mutex_unlock(&job->mu);
+    }
+  }
+  free(filename);
+  pthread_mutex_lock(&job->mu);
+  job->found += found;
+  job->ignored += ignored;
+  pthread_mutex_unlock(&job->mu);
+  return NULL;
+}
+
+int jur_tables_read_ascii(jur_tables_t *tb, ctl_t const *ctl) {
+  if (!tb || tb->ng < ctl->ng || tb->nd < ctl->nd) { jur_set_error("read_ascii: tables smaller than ctl"); return JUR_EINVAL; }
+  ascii_job_t job;
+  memset(&job, 0, sizeof job);
+  job.tb = tb; job.ctl = ctl;
+  pthread_mutex_init(&job.mu, NULL);
+  int nt = io_threads();
+  if (nt > ctl->ng * ctl->nd) nt = ctl->ng * ctl->nd;
+  pthread_t th[32];
+  int started = 0;
+  for (int i = 1; i < nt; i++)
+    if (pthread_create(&th[started], NULL, ascii_worker, &job) == 0) started++;
+  ascii_worker(&job);                                    /* the calling thread works too */
+  for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+  pthread_mutex_destroy(&job.mu);
+  tb->ignored_rows += job.ignored;
+  if (job.rc) { jur_set_error("%s", job.err); return job.rc; }
   if (tb->ignored_rows > 0)
     fprintf(stderr, "Warning! %ld table entries ignored (more than %d column densities per curve)\n",
             tb->ignored_rows, JUR_TBLNU);
-  return found;
+  return job.found;
 }
 
 /* Planck function as the reference evaluates it: C1 nu^3 / (exp(C2 nu / T) - 1)

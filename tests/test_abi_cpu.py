@@ -221,6 +221,43 @@ def test_fov_convolution_matches_the_restatement(oracle, tmp_path, descending):
         lib.fov_apply(np.zeros(1), np.array([10.0]), one_r, one_t, rdz, rw)
 
 
+def test_table_number_reader_equals_strtod():
+    """jur_parse_number (the reader of the .tab files) returns what strtod / sscanf("%lg") return, bit for bit:
+    the fast path for short decimals and the strtod fallback for everything else."""
+    L = lib.lib()
+    L.jur_parse_number.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double)]
+    L.jur_parse_number.restype = C.c_int
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([10.0 ** rng.uniform(-30, 30, 20000) * rng.choice([-1, 1], 20000),
+                           rng.uniform(0, 1, 5000), rng.integers(0, 10 ** 15, 5000).astype(float),
+                           [0.0, 1.0, 1e22, 1e23, 1e-22, 1e-23, 5e-324, 1.7976931348623157e308, 123456789012345.0,
+                            1234567890123456.0, 0.1, 1013.25, 6.02214199e23]])
+    texts = []
+    for v in vals:
+        for fmt in ("%g", "%.9g", "%.15g", "%.17g", "%e", "%.3f", "%.12e"):
+            texts.append(fmt % v)
+    texts += ["  42", "\t-7.5e3  ", "+3.", ".5", "1e5x", "0x1p3", "inf", "-INF", "nan", "1e400", "1e-400", "12abc", "1e", "1e+"]
+    for t in texts:
+        buf = C.c_char_p(t.encode())
+        out = C.c_double(0)
+        ok = L.jur_parse_number(C.byref(buf), C.byref(out))
+        try:                                                   # Python's float() is strtod minus partial tokens
+            want = float(t)
+        except ValueError:
+            want = None
+        if want is not None:
+            assert ok == 1, t
+            a, b = np.float64(out.value), np.float64(want)
+            assert (np.isnan(a) and np.isnan(b)) or a.view(np.uint64) == b.view(np.uint64), (t, out.value, want)
+    for t, lead in (("1e5x", 1e5), ("12abc", 12.0), ("1e", 1.0), ("1e+", 1.0)):   # strtod stops where the number ends
+        buf = C.c_char_p(t.encode())
+        out = C.c_double(0)
+        assert L.jur_parse_number(C.byref(buf), C.byref(out)) == 1 and out.value == lead, t
+    for t in ("", "   ", "abc", "-", "."):
+        buf = C.c_char_p(t.encode())
+        assert L.jur_parse_number(C.byref(buf), C.byref(C.c_double(0))) == 0, t
+
+
 def test_compute_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
