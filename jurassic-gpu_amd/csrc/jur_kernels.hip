@@ -138,9 +138,13 @@ __device__ __forceinline__ int locate_axis_from(double const *__restrict__ xx, i
 }
 
 // pressure and temperature of the profile slice [i0, i0+n) at altitude z0 (jr_common.h:549-555);
-// `hint` carries the bracket from call to call (dir == 0: exact bisection, axis not sorted)
+// `hint` carries the bracket from call to call (dir == 0: exact bisection, axis not sorted).
+// WANT_R: the caller interpolates more quantities on the same bracket; for a sorted axis (dir != 0: z strictly
+// monotone, bracket width non-zero) it gets rdz = RN(1 / (zb - za)) and every such interpolation, the
+// temperature's included, divides through it (lip_rcp: the same doubles, 3 instructions per quotient).
+template <bool WANT_R = false>
 __device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, double z0, double &p, double &t, int dir,
-                                         int &hint) {
+                                         int &hint, double *rdz = nullptr) {
   int const loc = dir ? locate_axis_from(v.atm_z + i0, n, z0, dir, hint) : locate_axis(v.atm_z + i0, n, z0);
   hint = loc;
   int const ip = i0 + loc;
@@ -148,8 +152,15 @@ __device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, dou
   // eip (jr_common.h:53-57) with log(p1/p0)/(z1-z0) taken from the per-level array that
   // jur_pslope_kernel filled with exactly that expression; NaN marks a non-positive pressure
   double const sl = v.atm_pslope[ip];
-  p = (sl == sl) ? v.atm_p[ip] * exp(sl * (z0 - za)) : lip(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0);
-  t = lip(za, v.atm_t[ip], zb, v.atm_t[ip + 1], z0);
+  if (WANT_R && dir) {
+    double const r = 1. / (zb - za);
+    *rdz = r;
+    p = (sl == sl) ? v.atm_p[ip] * exp(sl * (z0 - za)) : lip_rcp(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0, r);
+    t = lip_rcp(za, v.atm_t[ip], zb, v.atm_t[ip + 1], z0, r);
+  } else {
+    p = (sl == sl) ? v.atm_p[ip] * exp(sl * (z0 - za)) : lip(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0);
+    t = lip(za, v.atm_t[ip], zb, v.atm_t[ip + 1], z0);
+  }
   return ip;
 }
 
@@ -331,21 +342,24 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
         ds = 0.;
       }
 
-      double p, t;
-      int const ia = intpol_pt(v, atm0, atmn, z, p, t, zdir, zhint);
+      double p, t, rdz = 0;
+      int const ia = intpol_pt<true>(v, atm0, atmn, z, p, t, zdir, zhint, &rdz);
       double const dsn = (np >= 1) ? 0.5 * (ds_p + ds) : ds * 0.5;   // redone for the point before the exit
       F(JUR_F_DS, np) = dsn;
       {  // remaining quantities on the same bracket (jr_common.h:557-567)
         double const za = v.atm_z[ia], zb = v.atm_z[ia + 1];
+        double const kt = JUR_BOLTZMANN * t, rkt = 1. / kt;   // one division for all emitters' columns (div_rcp)
         for (int ig = 0; ig < v.ng; ig++) {
           double const *q = v.atm_q + (size_t)ig * v.atm_np;
-          double const qv = lip(za, q[ia], zb, q[ia + 1], z);
-          F(f_u + ig, np) = 10. * qv * p / (JUR_BOLTZMANN * t) * dsn;
+          double qv;
+          if (zdir) qv = lip_rcp(za, q[ia], zb, q[ia + 1], z, rdz); else qv = lip(za, q[ia], zb, q[ia + 1], z);
+          F(f_u + ig, np) = div_rcp(10. * qv * p, kt, rkt) * dsn;
           if (ig == v.ig_h2o) F(JUR_F_QH2O, np) = qv;
         }
         for (int iw = 0; iw < v.nw; iw++) {
           double const *k = v.atm_k + (size_t)iw * v.atm_np;
-          F(f_k + iw, np) = lip(za, k[ia], zb, k[ia + 1], z);
+          if (zdir) F(f_k + iw, np) = lip_rcp(za, k[ia], zb, k[ia + 1], z, rdz);
+          else F(f_k + iw, np) = lip(za, k[ia], zb, k[ia + 1], z);
         }
       }
       F(JUR_F_P, np) = p;
@@ -374,7 +388,8 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
         double xh[3], zz, llon, llat, pp, tt;
         for (int i = 0; i < 3; i++) xh[i] = x[i] + 0.5 * ds * ex0[i];
         cart2geo(xh, zz, llon, llat);
-        int const ib = intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
+        double rdzb = 0;
+        int const ib = intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb);
         double const n2 = refractivity(pp, tt);
         // the three displaced probes lie 0.02 km away: almost always in the bracket just found, whose six
         // values are then reused instead of being looked up and loaded again
@@ -388,20 +403,20 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
           bool const inside = (zdir > 0) ? ((zz >= za || first) && (zz < zb || lastb))
                             : (zdir < 0) ? ((zz < za || first) && (zz >= zb || lastb)) : false;
           if (inside) {
-            pp = (sl == sl) ? pa * exp(sl * (zz - za)) : lip(za, pa, zb, pb, zz);
-            tt = lip(za, ta, zb, tb, zz);
+            pp = (sl == sl) ? pa * exp(sl * (zz - za)) : lip_rcp(za, pa, zb, pb, zz, rdzb);   // inside => sorted axis
+            tt = lip_rcp(za, ta, zb, tb, zz, rdzb);
           } else {
             intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
           }
-          ngr[i] = (refractivity(pp, tt) - n2) / h;
+          ngr[i] = div_rcp(refractivity(pp, tt) - n2, h, 1. / h);
           xh[i] -= h;
         }
       }
       double ex1[3];
       for (int i = 0; i < 3; i++) ex1[i] = ex0[i] * n + ds * ngr[i];
-      double const norm_ex1 = norm3(ex1);
+      double const norm_ex1 = norm3(ex1), rnorm = 1. / norm_ex1;
       for (int i = 0; i < 3; i++) {
-        ex1[i] /= norm_ex1;
+        ex1[i] = div_rcp(ex1[i], norm_ex1, rnorm);
         x[i] += 0.5 * ds * (ex0[i] + ex1[i]);
         ex0[i] = ex1[i];
       }
