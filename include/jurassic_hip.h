@@ -88,7 +88,12 @@ void jur_model_destroy(jur_model_t *m);
 /* Upload the atmosphere (only atm->np points and ctl->ng gases travel).
  * Applies the hydrostatic adjustment first if ctl->hydz >= 0 -- on a private
  * copy; the caller's atm is not modified (GPU-path behaviour upstream,
- * GPUdrivers.cu:243). */
+ * GPUdrivers.cu:243).  An atmosphere identical to the one on the device is not
+ * uploaded again.
+ * Ordering: the upload waits for the stream of the model's last
+ * jur_formod_device call (whose kernels may still read the old atmosphere), so
+ * that stream handle must still be valid; calls enqueued on OTHER streams
+ * before that are the caller's to synchronise. */
 int  jur_model_set_atm(jur_model_t *m, atm_t const *atm);
 
 /* Forward model for nr rays, host arrays.  geom[7] = {time, obsz, obslon,
@@ -98,6 +103,12 @@ int  jur_model_set_atm(jur_model_t *m, atm_t const *atm);
  * each [nr].  np_out (optional) receives the number of LOS points per ray. */
 int  jur_formod_host(jur_model_t *m, long nr, double const *const geom[7],
                      double *rad, double *tau, double *const tp[3], int *np_out);
+
+/* jur_formod_host moves arrays that lie in pinned host memory (these allocators, hipHostMalloc,
+ * hipHostRegister) in place at PCIe speed and overlaps the transfers with the kernels; pageable arrays
+ * are staged through a pinned image inside the model (threaded memcpy).  NULL on failure. */
+void *jur_host_alloc(size_t bytes);
+void  jur_host_free(void *p);
 
 /* Same, all pointers in device memory of the model's GPU; work is enqueued on
  * `stream` (a hipStream_t, may be NULL) and the call returns without waiting.
@@ -156,6 +167,24 @@ int  jur_model_set_workspace_budget(jur_model_t *m, long bytes);
  * [0] jur_trace_kernel, [1] jur_ega_kernel, [2] jur_combine_kernel. */
 int  jur_model_enable_timing(jur_model_t *m, int on);
 int  jur_model_last_kernel_ms(jur_model_t *m, double out_ms[3], long out_launches[3]);
+
+/* ---- known-answer hooks (for tests; not on the product path) -------------------------------------------
+ * The device functions of the path evaluated on host arrays of n inputs, one element per lane, so that each can be
+ * checked against its reference counterpart at thresholds and range edges.
+ * jur_kat_ega_eps: ega_eps (jr_common.h:237-268) of pair (ig, id).  mode 0 = the reference's bisections,
+ *   1 = warm-started searches, 2 = + descriptors in LDS, 3 = + reciprocal bracket widths (what the bench runs);
+ *   JUR_EINVAL when the tables do not admit the mode.  chain != 0: one lane evaluates the n inputs in order,
+ *   carrying the search state from one to the next as the kernel does along a ray.
+ * jur_kat_continua: out[4][n] = continua_ctmco2/h2o/n2/o2 (jr_common.h:315-390) of channel id (0 outside a window).
+ * jur_kat_update: what 0: src[i] = src_planck_core(a[i]); (rad, tau)[i] updated by new_obs_core with
+ *   tau_gas = b[i], beta_ds = c[i] (jr_common.h:220-224, 293-300); what 1: add_surface_core with surface
+ *   temperature a[i] and, if b[i] != 0, brightness_core (jr_common.h:187-190, 227-234). */
+int jur_kat_ega_eps(jur_model_t *m, int ig, int id, long n, double const *tau, double const *t, double const *u,
+                    double const *p, int mode, int chain, double *out);
+int jur_kat_continua(jur_model_t *m, int id, long n, double const *p, double const *t, double const *q,
+                     double const *u_co2, double const *u_h2o, double *out);
+int jur_kat_update(jur_model_t *m, int id, long n, int what, double const *a, double const *b, double const *c,
+                   double *rad, double *tau, double *src);
 
 #ifdef __cplusplus
 }

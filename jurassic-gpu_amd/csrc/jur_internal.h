@@ -101,6 +101,14 @@ long jurk_sort_tmp_bytes(long nr);
 int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, double const *d_geom, int *d_order, void *tmp,
                    long tmp_bytes, void *stream);
 
+/* known-answer hooks (tests): device functions on arrays, see jurassic_hip.h */
+int jurk_kat_ega(jur_view_t const *v, int g, int d, long n, double const *tau, double const *t, double const *u, double const *p,
+                 int mode, int chain, double *out, void *stream);
+int jurk_kat_continua(jur_view_t const *v, int d, long n, double const *p, double const *t, double const *q, double const *u_co2,
+                      double const *u_h2o, double *out, void *stream);
+int jurk_kat_update(jur_view_t const *v, int d, long n, int what, double const *a, double const *b, double const *c, double *rad,
+                    double *tau, double *src, void *stream);
+
 /* host tables (jur_tables.c) */
 typedef struct {
   double t;

@@ -784,6 +784,48 @@ __device__ __forceinline__ double planck_src(double const *__restrict__ sr, doub
   return sr[it] + (t - st0) * (sr[it + 1] - sr[it]) * 4.0;
 }
 
+// radiance update of one segment (new_obs_core, jr_common.h:293-300)
+__device__ __forceinline__ void new_obs_step(double tau_gas, double beta_ds, double src, double &rad, double &tau) {
+  if (tau_gas > 1e-50) {
+    double const eps = 1. - tau_gas * exp(-beta_ds);
+    rad += src * eps * tau;
+    tau *= (1. - eps);
+  }
+}
+
+// after the last segment: surface emission if the ray hit the ground (add_surface_core, jr_common.h:227-234),
+// brightness temperature if asked for (brightness_core, :187-190)
+__device__ __forceinline__ void ray_epilogue(double const *__restrict__ sr, double nu, double tsurf, int write_bbt, double &rad,
+                                             double const tau) {
+  if (tsurf > 0.) rad += planck_src(sr, tsurf) * tau;
+  if (write_bbt) rad = JUR_C2 * nu / log1p((JUR_C1 * nu * nu * nu) / rad);
+}
+
+// Stage the level and curve descriptors (16 B each) of one (gas, channel) pair in LDS, once per workgroup, with
+// the reciprocal widths of the p and T brackets when the tables are strictly increasing (RCPB).  Ends in a barrier.
+template <bool LDS, bool RCPB>
+__device__ __forceinline__ void stage_pair(jur_view_t const &v, jur_int2 const pd, PairDesc<LDS> &D) {
+  if (LDS) {
+    Lvl const *const gl = reinterpret_cast<Lvl const *>(v.lvl) + pd.b;
+    Lvl const first = gl[0], last = gl[pd.a - 1];
+    D.kbase = (unsigned)first.c0;
+    int const ncrv = last.c0 + last.nt - first.c0;
+    Lvl *const sl = reinterpret_cast<Lvl *>(jur_lds);
+    Crv *const sc = reinterpret_cast<Crv *>(jur_lds + JUR_TBLNP * sizeof(Lvl));
+    Crv const *const gc = reinterpret_cast<Crv const *>(v.crv) + first.c0;
+    for (int i = threadIdx.x; i < pd.a; i += blockDim.x) sl[i] = gl[i];
+    for (int i = threadIdx.x; i < ncrv; i += blockDim.x) sc[i] = gc[i];
+    if (RCPB) {  // reciprocal widths of the p and T brackets (entries that straddle two axes are never used)
+      D.rp_off = (unsigned)((JUR_TBLNP + v.max_pair_curves) * 16);
+      D.rt_off = D.rp_off + (unsigned)(JUR_TBLNP * 8);
+      double *const rp = reinterpret_cast<double *>(jur_lds + D.rp_off), *const rt = reinterpret_cast<double *>(jur_lds + D.rt_off);
+      for (int i = threadIdx.x; i + 1 < pd.a; i += blockDim.x) rp[i] = 1. / (gl[i + 1].p - gl[i].p);
+      for (int i = threadIdx.x; i + 1 < ncrv; i += blockDim.x) rt[i] = 1. / (gc[i + 1].t - gc[i].t);
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // along-path integration in two kernels.  The emissivity-growth recurrence of every (ray, channel,
 // gas) triple is an independent sequential chain, so it gets its own lane -- ng x more lanes than
@@ -810,25 +852,7 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   jur_int2 const pd = v.pair[pair_idx];
   if (pd.a < 2) return;                          // no table: transmittance 1, the combine kernel knows
   PairDesc<LDS> D{v.lvl, v.crv, (unsigned)pd.b, 0u, 0u, 0u};
-  if (LDS) {  // stage the pair's level and curve descriptors (16 B each) once per workgroup
-    Lvl const *const gl = reinterpret_cast<Lvl const *>(v.lvl) + pd.b;
-    Lvl const first = gl[0], last = gl[pd.a - 1];
-    D.kbase = (unsigned)first.c0;
-    int const ncrv = last.c0 + last.nt - first.c0;
-    Lvl *const sl = reinterpret_cast<Lvl *>(jur_lds);
-    Crv *const sc = reinterpret_cast<Crv *>(jur_lds + JUR_TBLNP * sizeof(Lvl));
-    Crv const *const gc = reinterpret_cast<Crv const *>(v.crv) + first.c0;
-    for (int i = threadIdx.x; i < pd.a; i += blockDim.x) sl[i] = gl[i];
-    for (int i = threadIdx.x; i < ncrv; i += blockDim.x) sc[i] = gc[i];
-    if (RCPB) {  // reciprocal widths of the p and T brackets (entries that straddle two axes are never used)
-      D.rp_off = (unsigned)((JUR_TBLNP + v.max_pair_curves) * 16);
-      D.rt_off = D.rp_off + (unsigned)(JUR_TBLNP * 8);
-      double *const rp = reinterpret_cast<double *>(jur_lds + D.rp_off), *const rt = reinterpret_cast<double *>(jur_lds + D.rt_off);
-      for (int i = threadIdx.x; i + 1 < pd.a; i += blockDim.x) rp[i] = 1. / (gl[i + 1].p - gl[i].p);
-      for (int i = threadIdx.x; i + 1 < ncrv; i += blockDim.x) rt[i] = 1. / (gc[i + 1].t - gc[i].t);
-    }
-    __syncthreads();
-  }
+  stage_pair<LDS, RCPB>(v, pd, D);
   if (r >= c.n) return;
   size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
   size_t const Re = (size_t)c.stride_eps, fe = (size_t)NLOS * Re;
@@ -898,16 +922,9 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
     double tau_gas = 1.0;
     for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
       if ((has_table >> g) & 1u) tau_gas *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
-    double const src = planck_src(sr, t);
-    if (tau_gas > 1e-50) {  // jr_common.h:293-300
-      double const eps = 1. - tau_gas * exp(-beta_ds);
-      rad += src * eps * tau;
-      tau *= (1. - eps);
-    }
+    new_obs_step(tau_gas, beta_ds, planck_src(sr, t), rad, tau);
   }
-  double const tsurf = c.tsurf[r];
-  if (tsurf > 0.) rad += planck_src(sr, tsurf) * tau;
-  if (v.write_bbt) rad = JUR_C2 * ch.nu / log1p((JUR_C1 * ch.nu * ch.nu * ch.nu) / rad);
+  ray_epilogue(sr, ch.nu, c.tsurf[r], v.write_bbt, rad, tau);
   if (masked) rad = __builtin_nan("");
   c.rad[oidx] = rad;
   c.tau[oidx] = tau;
@@ -998,6 +1015,67 @@ __global__ __launch_bounds__(256) void jur_raykey_kernel(long nr, double const *
   id[r] = (int)r;
 }
 
+// ---------------------------------------------------------------------------------------
+// known-answer hooks (tests): the device functions above on arrays of inputs, one element per lane,
+// so that each can be compared with its reference counterpart at thresholds and range edges
+// (jr_common.h:239 tau < 1e-9, :295 tau_gas > 1e-50, continuum windows :318,345,367,381, extrapolation
+// beyond both ends of a curve) without a ray around it.  Not on the product path.
+// ---------------------------------------------------------------------------------------
+// chain != 0: ONE lane walks the n inputs in order and carries the warm-start state (br, ia, ib) from element
+// to element as jur_ega_kernel carries it from segment to segment -- the result of a look-up must not depend on
+// where the previous one left the brackets.
+template <bool WARM, bool LDS, bool RCPB>
+__global__ __launch_bounds__(256) void jur_kat_ega_kernel(jur_view_t v, int g, int d, long n, double const *__restrict__ tau,
+                                                          double const *__restrict__ t, double const *__restrict__ u,
+                                                          double const *__restrict__ p, int chain, double *__restrict__ out) {
+  jur_int2 const pd = v.pair[g * v.nd + d];
+  PairDesc<LDS> D{v.lvl, v.crv, (unsigned)pd.b, 0u, 0u, 0u};
+  if (pd.a >= 2) stage_pair<LDS, RCPB>(v, pd, D);       // uniform branch; stage_pair ends in a barrier
+  unsigned br = 0, ia = 0, ib = 0;
+  auto one = [&](long i) {
+    if constexpr (WARM) out[i] = ega_eps_warm<LDS, RCPB>(v, pd, D, tau[i], t[i], u[i], p[i], br, ia, ib);
+    else out[i] = ega_eps_exact<LDS>(v, pd, D, tau[i], t[i], u[i], p[i]);
+  };
+  if (chain) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      for (long i = 0; i < n; i++) one(i);
+  } else {
+    long const i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) one(i);
+  }
+}
+
+// out[0..3][n]: CO2, H2O, N2, O2 continuum terms of channel d as jur_combine_kernel adds them (0 outside a window)
+__global__ __launch_bounds__(256) void jur_kat_continua_kernel(jur_view_t v, int d, long n, double const *__restrict__ p,
+                                                               double const *__restrict__ t, double const *__restrict__ q,
+                                                               double const *__restrict__ u_co2, double const *__restrict__ u_h2o,
+                                                               double *__restrict__ out) {
+  long const i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  jur_chan_t const ch = v.chan[d];
+  out[i] = ch.co2_on ? ctm_co2(ch, p[i], t[i], u_co2[i]) : 0.;
+  out[n + i] = ch.h2o_on ? ctm_h2o(ch, p[i], t[i], q[i], u_h2o[i]) : 0.;
+  out[2 * n + i] = ch.n2_on ? ctm_n2(ch, p[i], t[i]) : 0.;
+  out[3 * n + i] = ch.o2_on ? ctm_o2(ch, p[i], t[i]) : 0.;
+}
+
+// what == 0: src = source function at t = a[i]; (rad, tau) updated by one segment with tau_gas = b[i], beta_ds = c[i]
+// what == 1: epilogue with surface temperature a[i] and brightness conversion if b[i] != 0; src = source at a[i]
+__global__ __launch_bounds__(256) void jur_kat_update_kernel(jur_view_t v, int d, long n, int what, double const *__restrict__ a,
+                                                             double const *__restrict__ b, double const *__restrict__ c,
+                                                             double *__restrict__ rad, double *__restrict__ tau,
+                                                             double *__restrict__ src) {
+  long const i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double const *const sr = v.sr + (size_t)d * TBLNS;
+  double r = rad[i], tt = tau[i];
+  src[i] = planck_src(sr, a[i]);
+  if (what == 0) new_obs_step(b[i], c[i], src[i], r, tt);
+  else ray_epilogue(sr, v.chan[d].nu, a[i], b[i] != 0., r, tt);
+  rad[i] = r;
+  tau[i] = tt;
+}
+
 }  // namespace
 
 extern "C" int jurk_prepare_atm(jur_view_t const *v, double *d_pslope, void *stream) {
@@ -1084,4 +1162,42 @@ extern "C" int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, doub
   e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, key_in, key_out, id_in, d_order, (int)nr, 0,
                                          by_profile ? 64 : 32, s);
   return (int)e;
+}
+
+// ---- known-answer hooks ----
+// mode 0: the reference's bisections; 1: warm-started searches, descriptors from global memory; 2: ... from LDS;
+// 3: LDS + reciprocal bracket widths (the variant the bench runs).  Returns hipErrorInvalidValue (1) when the
+// tables do not admit the mode.
+extern "C" int jurk_kat_ega(jur_view_t const *v, int g, int d, long n, double const *tau, double const *t, double const *u,
+                            double const *p, int mode, int chain, double *out, void *stream) {
+  if (n <= 0) return 0;
+  size_t const lds = (sizeof(jur_lvl_t) + 8) * JUR_TBLNP + (sizeof(jur_crv_t) + 8) * (size_t)v->max_pair_curves;
+  bool const lds_ok = v->max_pair_curves > 0 && lds <= 48 * 1024;
+  if ((mode >= 1 && !v->sorted_tables) || (mode >= 2 && !lds_ok) || (mode == 3 && !v->strict_tables) || mode < 0 || mode > 3)
+    return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 const grid(chain ? 1u : (unsigned)((n + 255) / 256)), block(256);
+  if (mode == 0) {
+    if (lds_ok) hipLaunchKernelGGL((jur_kat_ega_kernel<false, true, false>), grid, block, lds, s, *v, g, d, n, tau, t, u, p, chain, out);
+    else hipLaunchKernelGGL((jur_kat_ega_kernel<false, false, false>), grid, block, 0, s, *v, g, d, n, tau, t, u, p, chain, out);
+  } else if (mode == 1) hipLaunchKernelGGL((jur_kat_ega_kernel<true, false, false>), grid, block, 0, s, *v, g, d, n, tau, t, u, p, chain, out);
+  else if (mode == 2) hipLaunchKernelGGL((jur_kat_ega_kernel<true, true, false>), grid, block, lds, s, *v, g, d, n, tau, t, u, p, chain, out);
+  else hipLaunchKernelGGL((jur_kat_ega_kernel<true, true, true>), grid, block, lds, s, *v, g, d, n, tau, t, u, p, chain, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_kat_continua(jur_view_t const *v, int d, long n, double const *p, double const *t, double const *q,
+                                 double const *u_co2, double const *u_h2o, double *out, void *stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(jur_kat_continua_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *v, d, n, p, t,
+                     q, u_co2, u_h2o, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_kat_update(jur_view_t const *v, int d, long n, int what, double const *a, double const *b, double const *c,
+                               double *rad, double *tau, double *src, void *stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(jur_kat_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *v, d, n, what,
+                     a, b, c, rad, tau, src);
+  return (int)hipGetLastError();
 }

@@ -11,6 +11,7 @@
 #include <string.h>
 #include <strings.h>
 #include <pthread.h>
+#include <unistd.h>
 #include <hip/hip_runtime_api.h>
 #include "jur_internal.h"
 
@@ -57,7 +58,18 @@ struct jur_model {
   double *d_io;                 /* geom[7][cap] tp[3][cap] rad/tau[cap][nd]      */
   int *d_io_np;
   long io_cap;
+  double *h_io;                 /* pinned host image of d_io (+ np behind it) for callers with pageable arrays */
+  long h_io_cap;
+  double *h_pkg;                /* pinned scratch of the drop-in entry: rad/tau of one package, [2][NR][nd] */
+  double *h_atm;                /* host image of the atmosphere rows last uploaded (after the hydrostatic step) */
+  long h_atm_n, h_atm_cap;
+  double h_atm_hydz;
   hipStream_t stream;
+  hipStream_t stream2;          /* copies that run beside the kernels of `stream` */
+  hipEvent_t ev_mask, ev_trace, ev_side;
+  int host_call;                /* 1 while jur_formod_host drives jur_formod_device: record / wait for the events above */
+  void *last_stream;            /* stream of the last jur_formod_device call (see jur_model_set_atm) */
+  int have_last_stream;
   /* timing */
   int timing;
   hipEvent_t *evpool;           /* 2 events per timed launch                     */
@@ -88,6 +100,18 @@ static int check_ctl(ctl_t const *ctl) {
   if (ctl->formod == 1) { jur_set_error("FORMOD=1 (CGA) has no integrator upstream either"); return JUR_EINVAL; }
   for (int id = 0; id < ctl->nd; id++)
     if (ctl->window[id] < 0 || ctl->window[id] >= (ctl->nw > 0 ? ctl->nw : 1)) { jur_set_error("ctl->window[%d] out of range", id); return JUR_EINVAL; }
+  return JUR_OK;
+}
+
+static int create_streams(jur_model_t *m) {
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&m->ev_mask, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&m->ev_trace, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess) {
+    jur_set_error("cannot create the model's streams and events");
+    return JUR_EHIP;
+  }
   return JUR_OK;
 }
 
@@ -159,7 +183,8 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   v->ue = (jur_ue_t const *)m->d_ue;
 
   m->nfield = JUR_F_K + v->nw + v->ng;
-  m->chunk_rays = 1048576;      /* measured: 7.7 M rays/s at 1 M rays per launch vs 6.8 M at 131072 (tails, launch fill) */
+  m->chunk_rays = 1 << 21;      /* upper bound; the workspace budget sets the real size (1.4 M rays for 96 KB per ray).
+                                   Measured: 7.7 M rays/s at 1 M rays per launch vs 6.8 M at 131072 (tails, launch fill) */
   m->sort_rays = 1;
   m->ws_budget = 128L << 30;    /* of 288 GB HBM; C3 needs 96 KB per ray */
   m->trace_mult = 1;
@@ -167,7 +192,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   if (getenv("JUR_CHUNK_RAYS") && atoi(getenv("JUR_CHUNK_RAYS")) >= 64) m->chunk_rays = (atoi(getenv("JUR_CHUNK_RAYS")) + 63) / 64 * 64;
   if (getenv("JUR_TRACE_MULT") && atoi(getenv("JUR_TRACE_MULT")) >= 1) m->trace_mult = atoi(getenv("JUR_TRACE_MULT"));
   if (getenv("JUR_WS_GIB") && atoi(getenv("JUR_WS_GIB")) >= 1) m->ws_budget = (long)atoi(getenv("JUR_WS_GIB")) << 30;
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { jur_set_error("hipStreamCreate failed"); jur_model_destroy(m); return JUR_EHIP; }
+  if ((rc = create_streams(m))) { jur_model_destroy(m); return rc; }
   if ((rc = upload((void **)&m->d_status, NULL, sizeof(int)))) { jur_model_destroy(m); return rc; }
   HIPCHK(hipMemset(m->d_status, 0, sizeof(int)));
   *out = m;
@@ -213,7 +238,14 @@ void jur_model_destroy(jur_model_t *m) {
                   m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
     if (ptrs[i]) (void)hipFree(ptrs[i]);
+  if (m->h_io) (void)hipHostFree(m->h_io);
+  if (m->h_pkg) (void)hipHostFree(m->h_pkg);
+  free(m->h_atm);
   if (m->stream) (void)hipStreamDestroy(m->stream);
+  if (m->stream2) (void)hipStreamDestroy(m->stream2);
+  if (m->ev_mask) (void)hipEventDestroy(m->ev_mask);
+  if (m->ev_trace) (void)hipEventDestroy(m->ev_trace);
+  if (m->ev_side) (void)hipEventDestroy(m->ev_side);
   if (m->evpool) {
     for (int i = 0; i < 2 * JUR_MAX_TIMED; i++) (void)hipEventDestroy(m->evpool[i]);
     free(m->evpool);
@@ -293,7 +325,13 @@ static int upload_atm_rows(jur_model_t *m, double const *h, long n) {
     HIPCHK(hipMalloc(&m->d_atm, sizeof(double) * (nrow + 1) * (size_t)n));   /* + one row for atm_pslope */
     m->atm_cap = n;
   }
-  /* ordered behind earlier work on the model's stream */
+  /* Kernels of an earlier jur_formod_device call may still be reading the atmosphere on the CALLER's stream:
+   * wait for that stream first (the handle must still be valid -- see jurassic_hip.h).  Work on the model's own
+   * stream (jur_formod_host, the drop-in entry) is ordered by the stream itself. */
+  if (m->have_last_stream && (hipStream_t)m->last_stream != m->stream) {
+    HIPCHK(hipStreamSynchronize((hipStream_t)m->last_stream));
+    m->have_last_stream = 0;
+  }
   HIPCHK(hipMemcpyAsync(m->d_atm, h, sizeof(double) * nrow * (size_t)n, hipMemcpyHostToDevice, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
   double const *time = h, *z = h + (size_t)n;
@@ -331,45 +369,95 @@ int jur_model_set_atm(jur_model_t *m, atm_t const *atm) {
   double *h = (double *)malloc(sizeof(double) * nrow * n);
   if (!h) return JUR_ENOMEM;
   pack_atm_rows(m, atm, h, (size_t)n, 0);
+  /* The same atmosphere again (a caller looping over observation packages, formod.c:100, or the lanes of the
+   * drop-in entry): what is on the device already is what this upload would put there.  Compared before the
+   * hydrostatic step, which is a function of these rows and ctl->hydz. */
+  if (m->h_atm && m->h_atm_n == n && m->h_atm_hydz == m->ctl->hydz && m->view.atm_np == n &&
+      0 == memcmp(m->h_atm, h, sizeof(double) * nrow * n)) {
+    free(h);
+    return JUR_OK;
+  }
+  if ((long)(nrow * n) > m->h_atm_cap) {
+    free(m->h_atm);
+    m->h_atm = (double *)malloc(sizeof(double) * nrow * n);
+    m->h_atm_cap = m->h_atm ? (long)(nrow * n) : 0;
+  }
+  m->h_atm_n = 0;
+  if (m->h_atm) { memcpy(m->h_atm, h, sizeof(double) * nrow * n); m->h_atm_n = n; m->h_atm_hydz = m->ctl->hydz; }
   hydrostatic_rows(m, h, (size_t)n, 0, n);   /* on the private copy; the caller's atm is not modified */
   int const rc = upload_atm_rows(m, h, n);
+  if (rc) m->h_atm_n = 0;
   free(h);
   return rc;
 }
 
 /* ---- workspace --------------------------------------------------------------- */
+static void free_workspace(jur_model_t *m) {
+  if (m->d_los) (void)hipFree(m->d_los);
+  if (m->d_eps) (void)hipFree(m->d_eps);
+  if (m->d_np) (void)hipFree(m->d_np);
+  if (m->d_tsurf) (void)hipFree(m->d_tsurf);
+  m->d_los = NULL; m->d_eps = NULL; m->d_np = NULL; m->d_tsurf = NULL; m->los_bytes = 0; m->ws_rays = 0; m->ws_trace_rays = 0;
+}
+
 static int ensure_workspace(jur_model_t *m, long nr) {
   /* bytes per ray: LOS fields (per traced ray), one double per (channel, gas, point) (per integrated ray).
    * Tracing is latency-bound and wants many rays per launch, so its launches cover Rt = trace_mult * R rays
    * while the ega/combine launches cover R. */
   long const per_ray_los = (long)sizeof(double) * m->nfield * JUR_NLOS;
   long const per_ray_eps = (long)sizeof(double) * m->view.nd * (m->view.ng > 0 ? m->view.ng : 1) * JUR_NLOS;
-  long R = m->chunk_rays;
-  long const fit = m->ws_budget / (per_ray_los + per_ray_eps);
-  if (R > fit) R = fit / 64 * 64;
-  if (nr < R) R = (nr + 63) / 64 * 64;
-  if (R < 64) R = 64;
-  long mult = m->trace_mult > 0 ? m->trace_mult : 1;
-  while (mult > 1 && (per_ray_los * mult + per_ray_eps) * R > m->ws_budget) mult--;
-  long Rt = R * mult;
-  if (nr < Rt) Rt = (nr + R - 1) / R * R;
-  if (R > m->ws_rays || Rt > m->ws_trace_rays) {
-    if (m->d_los) (void)hipFree(m->d_los);
-    if (m->d_eps) (void)hipFree(m->d_eps);
-    if (m->d_np) (void)hipFree(m->d_np);
-    if (m->d_tsurf) (void)hipFree(m->d_tsurf);
-    m->d_los = NULL; m->d_eps = NULL; m->d_np = NULL; m->d_tsurf = NULL; m->los_bytes = 0; m->ws_rays = 0; m->ws_trace_rays = 0;
-    HIPCHK(hipMalloc((void **)&m->d_los, (size_t)per_ray_los * Rt));
-    HIPCHK(hipMalloc((void **)&m->d_eps, (size_t)per_ray_eps * R));
-    HIPCHK(hipMalloc((void **)&m->d_np, sizeof(int) * Rt));
-    HIPCHK(hipMalloc((void **)&m->d_tsurf, sizeof(double) * Rt));
-    m->los_bytes = per_ray_los * Rt + per_ray_eps * R;
-    m->ws_rays = R;
-    m->ws_trace_rays = Rt;
+  long budget = m->ws_budget;
+  int asked = 0;
+  for (int attempt = 0;; attempt++) {
+    long R = m->chunk_rays;
+    long const fit = budget / (per_ray_los + per_ray_eps);
+    if (R > fit) R = fit / 64 * 64;
+    if (R < 64) R = 64;
+    if (nr <= R) R = (nr + 63) / 64 * 64;
+    else {  /* several launches: equal shares instead of full chunks and a short tail */
+      long const nchunk = (nr + R - 1) / R;
+      R = ((nr + nchunk - 1) / nchunk + 63) / 64 * 64;
+    }
+    long mult = m->trace_mult > 0 ? m->trace_mult : 1;
+    while (mult > 1 && (per_ray_los * mult + per_ray_eps) * R > budget) mult--;
+    long Rt = R * mult;
+    if (nr < Rt) Rt = (nr + R - 1) / R * R;
+    if (R <= m->ws_rays && Rt <= m->ws_trace_rays) {   /* the held workspace serves (smaller strides fit inside it) */
+      m->use_rays = R;
+      m->use_trace_rays = Rt;
+      return JUR_OK;
+    }
+    if (!asked) {  /* about to allocate: never plan beyond what the device can give right now (another allocator
+                      in the process may hold part of the HBM) */
+      size_t free_b = 0, total_b = 0;
+      asked = 1;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        long const avail = (long)free_b + m->los_bytes - (2L << 30);
+        if (avail > (64L << 20) && avail < budget) { budget = avail; continue; }
+      } else (void)hipGetLastError();
+    }
+    free_workspace(m);
+    hipError_t e = hipMalloc((void **)&m->d_los, (size_t)per_ray_los * Rt);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_eps, (size_t)per_ray_eps * R);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_np, sizeof(int) * Rt);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_tsurf, sizeof(double) * Rt);
+    if (e == hipSuccess) {
+      m->los_bytes = per_ray_los * Rt + per_ray_eps * R;
+      m->ws_rays = R;
+      m->ws_trace_rays = Rt;
+      m->use_rays = R;
+      m->use_trace_rays = Rt;
+      return JUR_OK;
+    }
+    (void)hipGetLastError();
+    free_workspace(m);
+    if (R <= 64 || attempt >= 24) {
+      jur_set_error("cannot allocate the workspace (%ld B per ray, even for %ld rays): %s", per_ray_los + per_ray_eps, R,
+                    hipGetErrorString(e));
+      return JUR_EHIP;
+    }
+    budget = (per_ray_los + per_ray_eps) * R / 2;   /* allocation refused: try again with half the rays per launch */
   }
-  m->use_rays = R;
-  m->use_trace_rays = Rt;
-  return JUR_OK;
 }
 
 long jur_model_workspace_bytes(jur_model_t const *m) { return m->los_bytes; }
@@ -460,6 +548,8 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
   int rc = ensure_workspace(m, nr);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  m->last_stream = stream;
+  m->have_last_stream = 1;
   long const R = m->use_rays;
   int const *order = NULL;
   if (m->sort_rays && nr > 64) {
@@ -502,6 +592,13 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     c.tsurf = m->d_tsurf;
     c.los = m->d_los;
     TIMED(0, jurk_launch_trace(&m->view, &c, s), "trace");
+    if (m->host_call) {
+      /* host entry: the input radiances, which only the epilogue reads (NaN mask), are uploaded beside the first
+       * ray-tracing launch; tangent points and point counts are final after the last one and are copied out
+       * beside the integration */
+      if (t0 == 0) HIPCHK(hipStreamWaitEvent(s, m->ev_mask, 0));
+      if (t0 + Rt >= nr) HIPCHK(hipEventRecord(m->ev_trace, s));
+    }
     /* integrate it in chunks of R rays; slot s0 of the super-chunk is slot 0 of the chunk */
     for (long s0 = 0; s0 < nt; s0 += R) {
       c.n = (int)((nt - s0 < R) ? nt - s0 : R);
@@ -518,37 +615,158 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
   return JUR_OK;
 }
 
+/* ---- host entry ----------------------------------------------------------------- */
+/* Pinned allocations for callers that want their arrays to travel at PCIe speed without staging. */
+void *jur_host_alloc(size_t bytes) {
+  void *p = NULL;
+  if (hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    jur_set_error("hipHostMalloc of %zu bytes failed", bytes);
+    return NULL;
+  }
+  return p;
+}
+void jur_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+static int is_pinned(void const *p) {
+  hipPointerAttribute_t a;
+  if (!p) return 0;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return a.type == hipMemoryTypeHost;
+}
+
+/* memcpy spread over a few host threads: a pageable array of a million rays moves at one core's ~10 GB/s otherwise */
+typedef struct { char *dst; char const *src; size_t n; } cpjob_t;
+static void *cp_worker(void *a) { cpjob_t const *j = (cpjob_t const *)a; memcpy(j->dst, j->src, j->n); return NULL; }
+static void par_memcpy(void *dst, void const *src, size_t n) {
+  enum { MAXT = 8 };
+  int nt = 1;
+  if (n >= ((size_t)4 << 20)) {
+    long const ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    nt = (int)(n >> 21);
+    if (nt > MAXT) nt = MAXT;
+    if (ncpu > 0 && nt > ncpu) nt = (int)ncpu;
+  }
+  if (nt <= 1) { memcpy(dst, src, n); return; }
+  pthread_t th[MAXT];
+  cpjob_t job[MAXT];
+  size_t const per = ((n / nt) + 4095) & ~(size_t)4095;
+  int started = 0;
+  for (int i = 0; i < nt; i++) {
+    size_t const o = per * i;
+    if (o >= n) break;
+    job[i].dst = (char *)dst + o; job[i].src = (char const *)src + o; job[i].n = (n - o < per) ? n - o : per;
+    if (i == nt - 1 || o + per >= n || pthread_create(&th[started], NULL, cp_worker, &job[i]) != 0) {
+      job[i].n = n - o;                          /* last share (or no thread to be had): the rest, here */
+      memcpy(job[i].dst, job[i].src, job[i].n);
+      break;
+    }
+    started++;
+  }
+  for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+}
+
+/* device / pinned-host images of one call's arrays:
+ *   doubles: geom[7][nr] | rad[nr][nd] | tau[nr][nd] | tp[3][nr]   (inputs are a prefix, outputs a suffix)
+ *   ints:    np[nr] */
+static int ensure_io(jur_model_t *m, long nr, int want_host) {
+  int const nd = m->view.nd;
+  size_t const nval = (size_t)nr * (10 + 2 * (size_t)nd);
+  if (nr > m->io_cap) {
+    if (m->d_io) (void)hipFree(m->d_io);
+    if (m->d_io_np) (void)hipFree(m->d_io_np);
+    m->d_io = NULL; m->d_io_np = NULL; m->io_cap = 0;
+    HIPCHK(hipMalloc((void **)&m->d_io, sizeof(double) * nval));
+    HIPCHK(hipMalloc((void **)&m->d_io_np, sizeof(int) * (size_t)nr));
+    m->io_cap = nr;
+  }
+  if (want_host && nr > m->h_io_cap) {
+    if (m->h_io) (void)hipHostFree(m->h_io);
+    m->h_io = NULL; m->h_io_cap = 0;
+    HIPCHK(hipHostMalloc((void **)&m->h_io, sizeof(double) * nval + sizeof(int) * (size_t)nr, hipHostMallocDefault));
+    m->h_io_cap = nr;
+  }
+  return JUR_OK;
+}
+
+#define JUR_SMALL_CALL 65536   /* rays: below this one staged transfer each way beats overlapping several */
+
 int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double *rad, double *tau, double *const tp[3],
                     int *np_out) {
   if (!m || nr < 0) { jur_set_error("formod_host: bad arguments"); return JUR_EINVAL; }
   if (nr == 0) return JUR_OK;
   HIPCHK(hipSetDevice(m->device));
   int const nd = m->view.nd;
-  if (nr > m->io_cap) {
-    if (m->d_io) (void)hipFree(m->d_io);
-    if (m->d_io_np) (void)hipFree(m->d_io_np);
-    m->d_io = NULL; m->d_io_np = NULL; m->io_cap = 0;
-    HIPCHK(hipMalloc((void **)&m->d_io, sizeof(double) * (size_t)nr * (10 + 2 * (size_t)nd)));
-    HIPCHK(hipMalloc((void **)&m->d_io_np, sizeof(int) * (size_t)nr));
-    m->io_cap = nr;
+  size_t const N = (size_t)nr, nrd = N * nd;
+  hipStream_t const s = m->stream, s2 = m->stream2;
+  int status = 0, rc;
+
+  if (nr <= JUR_SMALL_CALL) {
+    /* a package: everything through the pinned image, one transfer in, one out */
+    if ((rc = ensure_io(m, nr, 1))) return rc;
+    double *const d_geom = m->d_io, *const d_rad = d_geom + 7 * N, *const d_tau = d_rad + nrd, *const d_tp = d_tau + nrd;
+    double *const h_geom = m->h_io, *const h_rad = h_geom + 7 * N, *const h_tau = h_rad + nrd, *const h_tp = h_tau + nrd;
+    int *const h_np = (int *)(h_tp + 3 * N);
+    for (int k = 0; k < 7; k++) memcpy(h_geom + k * N, geom[k], sizeof(double) * N);
+    memcpy(h_rad, rad, sizeof(double) * nrd);
+    HIPCHK(hipMemcpyAsync(d_geom, h_geom, sizeof(double) * (7 * N + nrd), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(m->d_status, 0, sizeof(int), s));
+    if ((rc = jur_formod_device(m, nr, d_geom, d_rad, d_tau, d_tp, m->d_io_np, m->d_status, s))) return rc;
+    HIPCHK(hipMemcpyAsync(h_rad, d_rad, sizeof(double) * (2 * nrd + 3 * N), hipMemcpyDeviceToHost, s));
+    if (np_out) HIPCHK(hipMemcpyAsync(h_np, m->d_io_np, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    memcpy(rad, h_rad, sizeof(double) * nrd);
+    memcpy(tau, h_tau, sizeof(double) * nrd);
+    for (int k = 0; k < 3; k++) memcpy(tp[k], h_tp + k * N, sizeof(double) * N);
+    if (np_out) memcpy(np_out, h_np, sizeof(int) * N);
+  } else {
+    /* a batch: copies run beside the kernels on a second stream.  Arrays the caller keeps in pinned memory
+     * (jur_host_alloc, hipHostMalloc, hipHostRegister) are transferred in place; pageable ones go through the
+     * model's pinned image with a threaded memcpy.
+     *   stream:  H2D geometry -> sort, trace | wait(mask) -> ega -> combine -> D2H rad, tau
+     *   stream2: H2D input rad (NaN mask, read by the epilogue only) ........ wait(trace) -> D2H tp, np    */
+    int pin_g[7], pin_tp[3], stage = 0;
+    for (int k = 0; k < 7; k++) stage |= !(pin_g[k] = is_pinned(geom[k]));
+    for (int k = 0; k < 3; k++) stage |= !(pin_tp[k] = is_pinned(tp[k]));
+    int const pin_rad = is_pinned(rad), pin_tau = is_pinned(tau), pin_np = np_out ? is_pinned(np_out) : 1;
+    stage |= !pin_rad | !pin_tau | !pin_np;
+    if ((rc = ensure_io(m, nr, stage))) return rc;
+    double *const d_geom = m->d_io, *const d_rad = d_geom + 7 * N, *const d_tau = d_rad + nrd, *const d_tp = d_tau + nrd;
+    double *const h_geom = m->h_io, *const h_rad = h_geom ? h_geom + 7 * N : NULL, *const h_tau = h_geom ? h_rad + nrd : NULL,
+           *const h_tp = h_geom ? h_tau + nrd : NULL;
+    int *const h_np = h_geom ? (int *)(h_tp + 3 * N) : NULL;
+    for (int k = 0; k < 7; k++) {
+      double const *src = geom[k];
+      if (!pin_g[k]) { par_memcpy(h_geom + k * N, geom[k], sizeof(double) * N); src = h_geom + k * N; }
+      HIPCHK(hipMemcpyAsync(d_geom + k * N, src, sizeof(double) * N, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipMemsetAsync(m->d_status, 0, sizeof(int), s));
+    {
+      double const *src = rad;
+      if (!pin_rad) { par_memcpy(h_rad, rad, sizeof(double) * nrd); src = h_rad; }
+      HIPCHK(hipMemcpyAsync(d_rad, src, sizeof(double) * nrd, hipMemcpyHostToDevice, s2));
+      HIPCHK(hipEventRecord(m->ev_mask, s2));
+    }
+    m->host_call = 1;
+    rc = jur_formod_device(m, nr, d_geom, d_rad, d_tau, d_tp, m->d_io_np, m->d_status, s);
+    m->host_call = 0;
+    if (rc) { (void)hipStreamSynchronize(s2); return rc; }
+    HIPCHK(hipStreamWaitEvent(s2, m->ev_trace, 0));
+    for (int k = 0; k < 3; k++)
+      HIPCHK(hipMemcpyAsync(pin_tp[k] ? tp[k] : h_tp + k * N, d_tp + k * N, sizeof(double) * N, hipMemcpyDeviceToHost, s2));
+    if (np_out) HIPCHK(hipMemcpyAsync(pin_np ? np_out : h_np, m->d_io_np, sizeof(int) * N, hipMemcpyDeviceToHost, s2));
+    HIPCHK(hipMemcpyAsync(pin_rad ? rad : h_rad, d_rad, sizeof(double) * nrd, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pin_tau ? tau : h_tau, d_tau, sizeof(double) * nrd, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s2));             /* tangent points are here while the integration still runs */
+    for (int k = 0; k < 3; k++)
+      if (!pin_tp[k]) par_memcpy(tp[k], h_tp + k * N, sizeof(double) * N);
+    if (np_out && !pin_np) par_memcpy(np_out, h_np, sizeof(int) * N);
+    HIPCHK(hipStreamSynchronize(s));
+    if (!pin_rad) par_memcpy(rad, h_rad, sizeof(double) * nrd);
+    if (!pin_tau) par_memcpy(tau, h_tau, sizeof(double) * nrd);
   }
-  double *d_geom = m->d_io, *d_tp = d_geom + 7 * (size_t)nr, *d_rad = d_tp + 3 * (size_t)nr,
-         *d_tau = d_rad + (size_t)nr * nd;
-  hipStream_t s = m->stream;
-  for (int k = 0; k < 7; k++)
-    HIPCHK(hipMemcpyAsync(d_geom + (size_t)k * nr, geom[k], sizeof(double) * nr, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(d_rad, rad, sizeof(double) * (size_t)nr * nd, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemsetAsync(m->d_status, 0, sizeof(int), s));
-  int rc = jur_formod_device(m, nr, d_geom, d_rad, d_tau, d_tp, m->d_io_np, m->d_status, s);
-  if (rc) return rc;
-  int status = 0;
-  for (int k = 0; k < 3; k++)
-    HIPCHK(hipMemcpyAsync(tp[k], d_tp + (size_t)k * nr, sizeof(double) * nr, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(rad, d_rad, sizeof(double) * (size_t)nr * nd, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(tau, d_tau, sizeof(double) * (size_t)nr * nd, hipMemcpyDeviceToHost, s));
-  if (np_out) HIPCHK(hipMemcpyAsync(np_out, m->d_io_np, sizeof(int) * nr, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(&status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
   if (status & 1) { jur_set_error("Too many LOS points! (a ray needs %d or more)", JUR_NLOS); return JUR_ENLOS; }
   return JUR_OK;
 }
@@ -618,6 +836,60 @@ done:
   if (d_np) (void)hipFree(d_np);
   if (d_out) (void)hipFree(d_out);
   return rc;
+}
+
+/* ---- known-answer hooks ----------------------------------------------------------- */
+/* nin input arrays and nout in/out arrays of n doubles each go to the device as one slab [nin + nout][n] */
+static int kat_slab(jur_model_t *m, long n, int nin, double const *const in[], int nout, double *const out[], double **d) {
+  *d = NULL;
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipMalloc((void **)d, sizeof(double) * (size_t)n * (size_t)(nin + nout)));
+  for (int k = 0; k < nin; k++) HIPCHK(hipMemcpy(*d + (size_t)k * n, in[k], sizeof(double) * n, hipMemcpyHostToDevice));
+  for (int k = 0; k < nout; k++) HIPCHK(hipMemcpy(*d + (size_t)(nin + k) * n, out[k], sizeof(double) * n, hipMemcpyHostToDevice));
+  return JUR_OK;
+}
+
+static int kat_finish(jur_model_t *m, int ek, long n, int nin, int nout, double *const out[], double *d) {
+  int rc = JUR_OK;
+  if (ek) { jur_set_error("known-answer kernel not launched: %s", hipGetErrorString((hipError_t)ek)); rc = (ek == (int)hipErrorInvalidValue) ? JUR_EINVAL : JUR_EHIP; }
+  if (!rc && hipStreamSynchronize(m->stream) != hipSuccess) { jur_set_error("known-answer kernel failed"); rc = JUR_EHIP; }
+  for (int k = 0; k < nout && !rc; k++)
+    if (hipMemcpy(out[k], d + (size_t)(nin + k) * n, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = JUR_EHIP;
+  if (d) (void)hipFree(d);
+  return rc;
+}
+
+int jur_kat_ega_eps(jur_model_t *m, int ig, int id, long n, double const *tau, double const *t, double const *u,
+                    double const *p, int mode, int chain, double *out) {
+  if (!m || n < 1 || ig < 0 || ig >= m->view.ng || id < 0 || id >= m->view.nd) { jur_set_error("kat_ega_eps: bad arguments"); return JUR_EINVAL; }
+  double const *in[4] = {tau, t, u, p};
+  double *io[1] = {out}, *d;
+  int rc = kat_slab(m, n, 4, in, 1, io, &d);
+  if (rc) { if (d) (void)hipFree(d); return rc; }
+  int const ek = jurk_kat_ega(&m->view, ig, id, n, d, d + n, d + 2 * n, d + 3 * n, mode, chain, d + 4 * n, m->stream);
+  return kat_finish(m, ek, n, 4, 1, io, d);
+}
+
+int jur_kat_continua(jur_model_t *m, int id, long n, double const *p, double const *t, double const *q, double const *u_co2,
+                     double const *u_h2o, double *out) {
+  if (!m || n < 1 || id < 0 || id >= m->view.nd) { jur_set_error("kat_continua: bad arguments"); return JUR_EINVAL; }
+  double const *in[5] = {p, t, q, u_co2, u_h2o};
+  double *io[4] = {out, out + n, out + 2 * n, out + 3 * n}, *d;
+  int rc = kat_slab(m, n, 5, in, 4, io, &d);
+  if (rc) { if (d) (void)hipFree(d); return rc; }
+  int const ek = jurk_kat_continua(&m->view, id, n, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 5 * n, m->stream);
+  return kat_finish(m, ek, n, 5, 4, io, d);
+}
+
+int jur_kat_update(jur_model_t *m, int id, long n, int what, double const *a, double const *b, double const *c, double *rad,
+                   double *tau, double *src) {
+  if (!m || n < 1 || id < 0 || id >= m->view.nd || (what != 0 && what != 1)) { jur_set_error("kat_update: bad arguments"); return JUR_EINVAL; }
+  double const *in[3] = {a, b, c};
+  double *io[3] = {rad, tau, src}, *d;
+  int rc = kat_slab(m, n, 3, in, 3, io, &d);
+  if (rc) { if (d) (void)hipFree(d); return rc; }
+  int const ek = jurk_kat_update(&m->view, id, n, what, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 5 * n, m->stream);
+  return kat_finish(m, ek, n, 3, 3, io, d);
 }
 
 /* ---- retrieval Jacobian -------------------------------------------------------- */
@@ -697,6 +969,7 @@ int jur_kernel(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t m
       hydrostatic_rows(m, h, NT, at, np0);
       for (int i = 0; i < np0; i++) h[at + i] = atm->time[i] + (double)j * span;
     }
+    m->h_atm_n = 0;                            /* the device no longer holds the caller's atmosphere */
     rc = upload_atm_rows(m, h, (long)NT);
     if (rc) goto done;
     double *geom[7], *tp[3], *rad, *tau;
@@ -774,8 +1047,11 @@ static jur_model_t *clone_lane(jur_model_t const *m) {
   c->los_bytes = 0; c->ws_rays = 0; c->ws_trace_rays = 0;
   c->d_order = NULL; c->d_sort_tmp = NULL; c->order_cap = 0; c->sort_tmp_bytes = 0;
   c->d_io = NULL; c->d_io_np = NULL; c->io_cap = 0;
-  c->stream = NULL; c->timing = 0; c->evpool = NULL; c->evkind = NULL; c->ntimed = 0;
-  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+  c->h_io = NULL; c->h_io_cap = 0; c->h_pkg = NULL; c->h_atm = NULL; c->h_atm_n = 0; c->h_atm_cap = 0;
+  c->stream = NULL; c->stream2 = NULL; c->ev_mask = NULL; c->ev_trace = NULL; c->ev_side = NULL;
+  c->host_call = 0; c->have_last_stream = 0; c->last_stream = NULL;
+  c->timing = 0; c->evpool = NULL; c->evkind = NULL; c->ntimed = 0;
+  if (hipSetDevice(c->device) != hipSuccess || create_streams(c) != JUR_OK ||
       hipMalloc((void **)&c->d_status, sizeof(int)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
     jur_model_destroy(c);
     return NULL;
@@ -790,6 +1066,10 @@ static void refresh_switches(jur_model_t *m, ctl_t const *ctl) {
   if (ctl->ng != v->ng || ctl->nd != v->nd) DIE("ng/nd changed after the tables were initialised");
   memcpy(m->ctl, ctl, sizeof(ctl_t));
   v->refrac = ctl->refrac; v->write_bbt = ctl->write_bbt; v->rayds = ctl->rayds; v->raydz = ctl->raydz;
+  /* upstream looks the emitters up on the first call that has the switch on, whichever call that is
+   * (CPUdrivers.c:126-128: `if (ctl->ctm_h2o && -999 == ig_h2o) ig_h2o = find_emitter(...)`) */
+  if (ctl->ctm_h2o && v->ig_h2o == -999) { v->ig_h2o = find_emitter(ctl, "H2O"); m->h_atm_n = 0; }   /* hydrostatic uses it */
+  if (ctl->ctm_co2 && v->ig_co2 == -999) v->ig_co2 = find_emitter(ctl, "CO2");
   v->fourbit = ((1 == ctl->ctm_co2) && (v->ig_co2 >= 0)) * 8 + ((1 == ctl->ctm_h2o) && (v->ig_h2o >= 0)) * 4
              + (1 == ctl->ctm_n2) * 2 + (1 == ctl->ctm_o2) * 1;
 }
@@ -845,8 +1125,9 @@ static void formod_range(ctl_t const *ctl, atm_t *atm, obs_t *obs, int r0, int n
   jur_model_t *m = g_lane[lane];
   if (jur_model_set_atm(m, atm) != JUR_OK) DIE("%s", jur_last_error());
   int const nd = ctl->nd;
-  double *buf = (double *)malloc(sizeof(double) * (size_t)nr * 2 * nd);
-  if (!buf) DIE("Out of memory!");
+  if (!m->h_pkg && hipHostMalloc((void **)&m->h_pkg, sizeof(double) * 2 * JUR_NR * (size_t)nd, hipHostMallocDefault) != hipSuccess)
+    DIE("Out of memory!");
+  double *const buf = m->h_pkg;                  /* the lane's package scratch, kept for the life of the process */
   double *rad = buf, *tau = buf + (size_t)nr * nd;
   for (int i = 0; i < nr; i++)
     for (int id = 0; id < nd; id++) rad[(size_t)i * nd + id] = obs->rad[r0 + i][id];
@@ -866,7 +1147,6 @@ static void formod_range(ctl_t const *ctl, atm_t *atm, obs_t *obs, int r0, int n
       obs->tau[r0 + i][id] = 1.0;
     }
   }
-  free(buf);
   release_lane(lane);
 }
 

@@ -51,6 +51,9 @@ def lib():
         L.jur_model_set_atm.argtypes = [C.c_void_p, C.c_void_p]
         L.jur_formod_host.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
         L.jur_curtis_godson_host.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), dp, dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
+        L.jur_host_alloc.restype = C.c_void_p
+        L.jur_host_alloc.argtypes = [C.c_size_t]
+        L.jur_host_free.argtypes = [C.c_void_p]
         L.jur_formod_device.argtypes = [C.c_void_p, C.c_long] + [C.c_void_p] * 7
         L.jur_model_reserve.argtypes = [C.c_void_p, C.c_long]
         L.jur_model_workspace_bytes.restype = C.c_long
@@ -68,6 +71,9 @@ def lib():
         L.jur_measurement_size.argtypes = [C.c_void_p, C.c_void_p]
         L.jur_kernel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, dp, C.c_size_t, C.c_size_t]
         L.jur_abi_sizes.argtypes = [C.POINTER(C.c_size_t)]
+        L.jur_kat_ega_eps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, dp, dp, dp, dp, C.c_int, C.c_int, dp]
+        L.jur_kat_continua.argtypes = [C.c_void_p, C.c_int, C.c_long] + [dp] * 6
+        L.jur_kat_update.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int] + [dp] * 6
         for name in ("formod", "formod_GPU"):
             getattr(L, name).argtypes = [C.c_void_p] * 3
             getattr(L, name).restype = None
@@ -133,6 +139,43 @@ class Tables:
         return self
 
 
+class HostBuffers:
+    """The arrays of one jur_formod_host call, allocated once and reused: geom (7, nr), rad/tau (nr, nd),
+    tp (3, nr), np (nr,) -- in pinned host memory (jur_host_alloc) or as ordinary numpy arrays."""
+
+    def __init__(self, nr, nd, pinned=True):
+        self.nr, self.nd, self.pinned = nr, nd, pinned
+        self._raw = []
+        self.geom = self._alloc((7, nr), np.float64)
+        self.rad = self._alloc((nr, nd), np.float64)
+        self.tau = self._alloc((nr, nd), np.float64)
+        self.tp = self._alloc((3, nr), np.float64)
+        self.np = self._alloc((nr,), np.int32)
+
+    def _alloc(self, shape, dtype):
+        if not self.pinned:
+            return np.zeros(shape, dtype=dtype)
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = lib().jur_host_alloc(n)
+        if not p:
+            raise JurassicError(lib().jur_last_error().decode())
+        self._raw.append(p)
+        a = np.frombuffer((C.c_char * n).from_address(p), dtype=dtype).reshape(shape)
+        a[...] = 0
+        return a
+
+    def set_geometry(self, geom):
+        self.geom[...] = np.asarray(geom, dtype=np.float64).T
+
+    def close(self):
+        self.geom = self.rad = self.tau = self.tp = self.np = None
+        for p in self._raw:
+            lib().jur_host_free(p)
+        self._raw = []
+
+    __del__ = close
+
+
 class Model:
     """Control block + tables resident on one GPU."""
 
@@ -184,6 +227,15 @@ class Model:
         _chk(lib().jur_formod_host(self.h, nr, garr, _p(rad), _p(tau), tarr, npts.ctypes.data_as(C.POINTER(C.c_int))))
         return dict(rad=rad, tau=tau, tp=np.ascontiguousarray(tp.T), np=npts)
 
+    def host_buffers(self, nr, pinned=True):
+        return HostBuffers(nr, self.nd, pinned)
+
+    def formod_host_buffers(self, b):
+        """jur_formod_host on preallocated arrays (b.rad is read for the NaN mask, then overwritten)."""
+        garr = (dp * 7)(*[_p(b.geom[k]) for k in range(7)])
+        tarr = (dp * 3)(*[_p(b.tp[k]) for k in range(3)])
+        _chk(lib().jur_formod_host(self.h, b.nr, garr, _p(b.rad), _p(b.tau), tarr, b.np.ctypes.data_as(C.POINTER(C.c_int))))
+
     def curtis_godson(self, geom):
         """-> dict(cgp, cgt, cgu (nr, ng, NLOS), np)."""
         g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
@@ -206,6 +258,28 @@ class Model:
         k = np.zeros((m, n))
         _chk(lib().jur_kernel(self.h, C.byref(atm), C.byref(obs), _p(k), m, n))
         return k
+
+    # known-answer hooks: device functions on arrays (include/jurassic_hip.h)
+    def kat_ega_eps(self, ig, id_, tau, t, u, p, mode=3, chain=False):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (tau, t, u, p)]
+        out = np.zeros(len(a[0]))
+        _chk(lib().jur_kat_ega_eps(self.h, ig, id_, len(out), *[_p(x) for x in a], mode, int(chain), _p(out)))
+        return out
+
+    def kat_continua(self, id_, p, t, q, u_co2, u_h2o):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (p, t, q, u_co2, u_h2o)]
+        out = np.zeros((4, len(a[0])))
+        _chk(lib().jur_kat_continua(self.h, id_, out.shape[1], *[_p(x) for x in a], _p(out)))
+        return out
+
+    def kat_update(self, id_, what, a, b, c, rad, tau):
+        """what 0: one segment (a = T, b = tau_gas, c = beta_ds); what 1: epilogue (a = tsurf, b = bbt flag).
+        -> (rad, tau, src)"""
+        a, b, c = (np.ascontiguousarray(x, dtype=np.float64) for x in (a, b, c))
+        rad, tau = np.array(rad, dtype=np.float64), np.array(tau, dtype=np.float64)
+        src = np.zeros(len(a))
+        _chk(lib().jur_kat_update(self.h, id_, len(a), what, _p(a), _p(b), _p(c), _p(rad), _p(tau), _p(src)))
+        return rad, tau, src
 
     def enable_timing(self, on=True):
         _chk(lib().jur_model_enable_timing(self.h, int(on)))

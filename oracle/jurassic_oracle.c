@@ -429,6 +429,21 @@ static inline double src_planck_core(orc_tbl_t const *tb, double t, int id) {
   return lip(tb->st[it], T_SR(tb, it, id), tb->st[it + 1], T_SR(tb, it + 1, id), t);
 }
 
+/* function-level entries for known-answer tests */
+double orc_src_planck(orc_tbl_t const *tb, double t, int id) { return src_planck_core(tb, t, id); }
+
+void orc_new_obs(double tau_gas, double beta_ds, double src, double *rad, double *tau) {   /* new_obs_core, jr_common.h:293-300 */
+  if (tau_gas > 1e-50) {
+    double const eps = 1. - tau_gas * exp(-beta_ds);
+    *rad += src * eps * (*tau);
+    *tau *= (1. - eps);
+  }
+}
+
+void orc_add_surface(orc_tbl_t const *tb, double tsurf, int id, double *rad, double tau) {  /* add_surface_core, :227-234 */
+  if (tsurf > 0.) *rad += src_planck_core(tb, tsurf, id) * tau;
+}
+
 double orc_brightness(double rad, double nu) {        /* brightness_core */
   return JUR_C2 * nu / log1p((JUR_C1 * nu * nu * nu) / rad);
 }

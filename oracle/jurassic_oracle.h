@@ -106,6 +106,9 @@ double orc_ctmh2o(double nu, double p, double t, double q, double u);
 double orc_ctmn2(double nu, double p, double t);
 double orc_ctmo2(double nu, double p, double t);
 double orc_planck(double t, double nu);
+double orc_src_planck(orc_tbl_t const *tbl, double t, int id);                         /* src_planck_core, jr_common.h:220-224 */
+void   orc_new_obs(double tau_gas, double beta_ds, double src, double *rad, double *tau);   /* new_obs_core, :293-300 */
+void   orc_add_surface(orc_tbl_t const *tbl, double tsurf, int id, double *rad, double tau);   /* add_surface_core, :227-234 */
 double orc_brightness(double rad, double nu);
 /* One line of sight: returns np, fills SoA outputs of length JUR_NLOS
  * (q/u are [JUR_NG][JUR_NLOS]); tp[3] = tpz,tplon,tplat. */

@@ -53,6 +53,12 @@ def lib():
             if n:
                 f.argtypes = [C.c_double] * n
         L.orc_ega_eps.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_int, C.c_int]
+        L.orc_src_planck.restype = C.c_double
+        L.orc_src_planck.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        L.orc_new_obs.restype = None
+        L.orc_new_obs.argtypes = [C.c_double] * 3 + [dp, dp]
+        L.orc_add_surface.restype = None
+        L.orc_add_surface.argtypes = [C.c_void_p, C.c_double, C.c_int, dp, C.c_double]
         L.orc_traceray.restype = C.c_int
         L.orc_traceray.argtypes = [C.c_void_p, C.c_void_p] + [dp] * 12
         L.orc_hydrostatic.argtypes = [C.c_void_p, C.c_void_p]
@@ -131,6 +137,44 @@ def algorithmic_bytes(ctl, atm, tables, geom):
                                     *[_p(g[k]) for k in range(7)], C.byref(nseg), C.byref(tr), C.byref(eg))
     return dict(total=b, trace=tr.value, ega=eg.value, combine=b - tr.value - eg.value,
                 integrate=b - tr.value, segments=nseg.value, rays=g.shape[1])
+
+
+def ega_eps(tables, ig, id_, tau, t, u, p):
+    """ega_eps (jr_common.h:237-268) element by element."""
+    f = lib().orc_ega_eps
+    return np.array([f(tables.h, a, b, c, d, ig, id_) for a, b, c, d in zip(tau, t, u, p)])
+
+
+def continua(nu, p, t, q, u_co2, u_h2o):
+    """(4, n): continua_ctmco2 / ctmh2o / ctmn2 / ctmo2 (jr_common.h:315-390) at wavenumber nu."""
+    L = lib()
+    return np.array([[L.orc_ctmco2(nu, a, b, d) for a, b, d in zip(p, t, u_co2)],
+                     [L.orc_ctmh2o(nu, a, b, c, e) for a, b, c, e in zip(p, t, q, u_h2o)],
+                     [L.orc_ctmn2(nu, a, b) for a, b in zip(p, t)],
+                     [L.orc_ctmo2(nu, a, b) for a, b in zip(p, t)]])
+
+
+def new_obs(tables, id_, t, tau_gas, beta_ds, rad, tau):
+    """src_planck_core + new_obs_core per element -> (rad, tau, src)."""
+    L = lib()
+    rad, tau = np.array(rad, dtype=np.float64), np.array(tau, dtype=np.float64)
+    src = np.array([L.orc_src_planck(tables.h, x, id_) for x in t])
+    for i in range(len(t)):
+        r, tt = C.c_double(rad[i]), C.c_double(tau[i])
+        L.orc_new_obs(tau_gas[i], beta_ds[i], src[i], C.byref(r), C.byref(tt))
+        rad[i], tau[i] = r.value, tt.value
+    return rad, tau, src
+
+
+def epilogue(tables, id_, nu, tsurf, bbt, rad, tau):
+    """add_surface_core, then brightness_core where bbt != 0 -> rad."""
+    L = lib()
+    rad = np.array(rad, dtype=np.float64)
+    for i in range(len(rad)):
+        r = C.c_double(rad[i])
+        L.orc_add_surface(tables.h, tsurf[i], id_, C.byref(r), tau[i])
+        rad[i] = L.orc_brightness(r.value, nu) if bbt[i] else r.value
+    return rad
 
 
 def traceray(ctl, atm, geom7):

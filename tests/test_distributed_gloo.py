@@ -1,5 +1,12 @@
-"""N > 1 path on CPU: two gloo ranks shard the rays, compute their shard (with
-the oracle standing in for the GPU kernels) and gather obs.rad on rank 0."""
+"""N > 1 path on CPU (gloo): the sharding / gather code bench.py runs, and bench.py's own launcher.
+
+* two gloo ranks shard a ragged ray set with shard.ray_range, compute their shard (the oracle standing in for
+  the GPU kernels) and gather obs.rad on rank 0 with shard.gather_rows;
+* `python3 bench.py --gpus 2 --dry-run` must start its two ranks itself -- as child processes, from a parent
+  that never imported torch -- shard one global ray set, gather, verify and relay ONE JSON line with n_gpus 2;
+* a world size that differs from --gpus is an error, never a silent 1-GPU run.
+"""
+import json
 import os
 import subprocess
 import sys
@@ -21,15 +28,18 @@ WORKER = textwrap.dedent("""
     case = common.limb_case(geom=geom)
     lo, hi = shard.ray_range(rank, world, n)
     res = orc.formod_rays(case.ctl, case.atm, case.oracle_tables(orc), geom[lo:hi])
-    counts = [shard.ray_range(r, world, n)[1] - shard.ray_range(r, world, n)[0] for r in range(world)]
-    full = shard.gather_rows(torch.from_numpy(res['rad']), counts, dst=0)
+    counts = shard.ray_counts(world, n)
+    out = torch.full((n, 2), -1.0, dtype=torch.float64) if rank == 0 else None
+    full = shard.gather_rows(torch.from_numpy(res['rad']), counts, dst=0, out=out)
+    again = shard.gather_rows(torch.from_numpy(res['rad']), counts, dst=0)          # without a preallocated buffer
     if rank == 0:
         ref = orc.formod_rays(case.ctl, case.atm, case.oracle_tables(orc), geom)
-        assert full.shape == (n, 2), full.shape
+        assert full is out and full.shape == (n, 2), full.shape
         assert np.array_equal(full.numpy(), ref['rad'])
+        assert np.array_equal(again.numpy(), ref['rad'])
         print('GATHER_OK', counts)
     else:
-        assert full is None
+        assert full is None and again is None
     dist.destroy_process_group()
 """)
 
@@ -53,3 +63,50 @@ def test_ray_ranges_partition_exactly():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+            assert shard.ray_counts(w, n) == [h - l for l, h in r]
+
+
+def _bench(*argv, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    e.update(OMP_NUM_THREADS="2", **(env or {}))
+    return subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                          env=e, timeout=900)
+
+
+def test_bench_starts_its_own_ranks():
+    """What the round-1 bench could not do: `bench.py --gpus 2` without torchrun."""
+    out = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--rays", "2001", "--dry-run")
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout                               # exactly one JSON line on stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["dry_run"] is True
+    assert doc["config"]["workload"] == "limb_1e7_sharded"           # configs[3]: one global set, sharded
+    assert doc["config"]["rays_total"] == 2001 and doc["config"]["rays_per_gpu"] == [1000, 1001]
+    kids = doc["launcher"]["children"]
+    assert [k["rank"] for k in kids] == [0, 1] and [k["local_rank"] for k in kids] == [0, 1]
+    assert all(k["world_size"] == 2 for k in kids)
+    assert [k["rays"] for k in kids] == [[0, 1000], [1000, 2001]]
+    pids = {k["pid"] for k in kids}
+    assert len(pids) == 2 and doc["launcher"]["parent_pid"] not in pids      # two children, neither is the parent
+    assert doc["launcher"]["parent_imported_torch"] is False                 # the parent never came near a GPU
+    assert doc["gather_check"]["differing_values"] == 0 and doc["gather_check"]["sampled_rays"] > 1000
+    assert doc["scaling"] == "strong" and doc["value"] > 0
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    """--gpus 8 inside a 1-rank world (or the reverse) must fail, not measure one GPU."""
+    out = _bench("--gpus", "2", "--dry-run", "--rays", "100",
+                 env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655"))
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+    assert not out.stdout.strip()
+    out = _bench("--gpus", "1", "--dry-run", "--rays", "100",
+                 env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29656"))
+    assert out.returncode != 0 and not out.stdout.strip()
+
+
+def test_bench_dry_run_single_rank_line():
+    out = _bench("--dry-run", "--rays", "500", "--steps", "1", "--warmup", "0")
+    assert out.returncode == 0, out.stdout + out.stderr
+    doc = json.loads(out.stdout.strip())
+    assert doc["n_gpus"] == 1 and doc["config"]["workload"] == "limb_1e6" and doc["config"]["rays_per_gpu"] == [500]

@@ -1,0 +1,185 @@
+"""Function-level known-answer tests ON THE DEVICE (SURVEY.md section 4 "what the build must add", section 8c plan
+item 2): the device functions of the hot path, evaluated one element per lane through the jur_kat_* hooks of the
+C-ABI, against the oracle's restatement of the same reference function -- at the thresholds and range edges the
+end-to-end parity tests only reach by chance:
+
+  ega_eps            jr_common.h:237-268  tau around the 1e-9 gate, tau = 1, p and T below / on / above every axis
+                                          end, u = 0 and u beyond both ends of a curve; all four search strategies
+  continua_ctm*      jr_common.h:315-390  channels exactly on 2120 / 2605 / 1360 / 1805 / 820 / 960 / 4000 cm^-1
+  src_planck_core    jr_common.h:220-224  T = 100 K, 399.99 K, grid points
+  new_obs_core       jr_common.h:293-300  tau_gas around the 1e-50 gate
+  add_surface_core / brightness_core      jr_common.h:187-190, 227-234
+
+The look-up is plain IEEE arithmetic in the reference's operand order, so ega_eps must come back BIT-IDENTICAL in
+every mode; functions that call exp / tanh / pow / log1p are held to a few ulp of the device math library.
+"""
+import os
+import numpy as np
+import pytest
+import common
+from jurassic_hip import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from jurassic_hip import lib
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return lib
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def same_doubles(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.array_equal(bits(a)[~np.isnan(a)], bits(b)[~np.isnan(b)]) and np.array_equal(np.isnan(a), np.isnan(b))
+
+
+def around(x, k=2):
+    """x and its k neighbours in the doubles on either side."""
+    out, lo, hi = [x], x, x
+    for _ in range(k):
+        lo, hi = np.nextafter(lo, -np.inf), np.nextafter(hi, np.inf)
+        out += [lo, hi]
+    return out
+
+
+def ega_inputs(rows, seed, n_random=6000):
+    """Edge values of every argument of ega_eps for one table, all combinations of a few of them plus random draws."""
+    rng = np.random.default_rng(seed)
+    plev = np.unique(rows[:, 0])
+    tlev = np.unique(rows[:, 1])
+    plev = np.concatenate([plev, np.repeat(plev[-1:], max(0, 6 - len(plev)))])      # tiny tables: indices below stay valid
+    tlev = np.concatenate([tlev, np.repeat(tlev[-1:], max(0, 5 - len(tlev)))])
+    ulo, uhi = rows[:, 2].min(), rows[:, 2].max()
+    taus = around(1e-9) + [1.0, np.nextafter(1.0, 0), 1 - 1e-12, 0.999, 0.5, 1e-3, 1e-8, 3e-9, 0.0, 1e-10, 1e-300]
+    ps = [plev[0] * 0.1, np.nextafter(plev[0], 0), plev[0], np.nextafter(plev[0], 1e9), plev[1], plev[len(plev) // 2],
+          np.sqrt(plev[3] * plev[4]), np.nextafter(plev[-1], 0), plev[-1], np.nextafter(plev[-1], 1e9), plev[-1] * 1.2]
+    ts = [100.0, tlev[0] - 1e-9, tlev[0], tlev[1], 0.5 * (tlev[2] + tlev[3]), tlev[len(tlev) // 2], tlev[-1], tlev[-1] + 1e-9,
+          399.99]
+    us = [0.0, ulo * 1e-6, ulo, np.sqrt(ulo * uhi), uhi, uhi * 1e6, 1e30]
+    g = np.array(np.meshgrid(taus, ts, us, ps, indexing="ij")).reshape(4, -1)
+    r = np.stack([10.0 ** rng.uniform(-9.3, 0, n_random), rng.uniform(150, 360, n_random),
+                  10.0 ** rng.uniform(np.log10(ulo) - 3, np.log10(uhi) + 3, n_random),
+                  10.0 ** rng.uniform(np.log10(plev[0]) - 1, np.log10(plev[-1]) + 0.3, n_random)])
+    x = np.concatenate([g, r], axis=1)
+    x = x[:, rng.permutation(x.shape[1])]        # a shuffled order: the chained evaluation jumps across the whole table
+    return x[0], x[1], x[2], x[3]
+
+
+def test_ega_eps_at_gates_and_axis_ends_is_bit_identical_in_every_mode(hip, oracle):
+    case = common.limb_case()                                # 5 emitters x 2 channels, sorted strictly increasing tables
+    m = hip.Model(case.ctl, case.lib_tables())
+    ot = case.oracle_tables(oracle)
+    for ig, id_ in ((0, 0), (2, 1), (4, 0)):
+        tau, t, u, p = ega_inputs(case.rows[(ig, id_)], seed=10 * ig + id_)
+        ref = oracle.ega_eps(ot, ig, id_, tau, t, u, p)
+        assert np.all(ref[tau < 1e-9] == 0.0) and np.any(tau < 1e-9) and np.any(ref[tau >= 1e-9] > 0)     # the gate itself
+        for mode in (0, 1, 2, 3):
+            got = m.kat_ega_eps(ig, id_, tau, t, u, p, mode=mode)
+            bad = np.nonzero(bits(got) != bits(ref))[0]
+            assert len(bad) == 0, (mode, ig, id_, len(bad), tau[bad[:3]], t[bad[:3]], u[bad[:3]], p[bad[:3]], got[bad[:3]], ref[bad[:3]])
+        # the searches resume from wherever the previous look-up ended: the result must not depend on that
+        k = 4000
+        for mode in (1, 2, 3):
+            got = m.kat_ega_eps(ig, id_, tau[:k], t[:k], u[:k], p[:k], mode=mode, chain=True)
+            assert same_doubles(got, ref[:k]), (mode, ig, id_)
+    # NaN inputs come back as the reference's comparisons hand them through
+    tau = np.array([0.5, np.nan, 0.5, 0.5, 0.5]); t = np.array([250.0, 250.0, np.nan, 250.0, 250.0])
+    u = np.array([1e18, 1e18, 1e18, np.nan, 1e18]); p = np.array([100.0, 100.0, 100.0, 100.0, np.nan])
+    ref = oracle.ega_eps(ot, 0, 0, tau, t, u, p)
+    for mode in (0, 1, 2, 3):
+        got = m.kat_ega_eps(0, 0, tau, t, u, p, mode=mode)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and got[0] == ref[0], (mode, got, ref)
+    m.close()
+
+
+@pytest.mark.parametrize("kw,modes", [(dict(table_kw=dict(dup_every=7)), (0, 1, 2)),        # sorted, not strictly: no reciprocal widths
+                                      (dict(table_kw=dict(descending=True)), (0,)),          # unsorted pressure axis: bisections only
+                                      (dict(table_kw=dict(nlev=2, ntemp=2)), (0, 1, 2, 3)),  # the smallest table that is looked up
+                                      (dict(table_kw=dict(nlev=1)), (0, 1, 2, 3))])          # np < 2: transparent, after the tau gate
+def test_ega_eps_other_table_shapes(hip, oracle, kw, modes):
+    case = common.limb_case(**kw)
+    m = hip.Model(case.ctl, case.lib_tables())
+    ot = case.oracle_tables(oracle)
+    tau, t, u, p = ega_inputs(case.rows[(1, 1)], seed=3, n_random=3000)
+    ref = oracle.ega_eps(ot, 1, 1, tau, t, u, p)
+    for mode in range(4):
+        if mode in modes:
+            assert same_doubles(m.kat_ega_eps(1, 1, tau, t, u, p, mode=mode), ref), mode
+        else:
+            with pytest.raises(hip.JurassicError):
+                m.kat_ega_eps(1, 1, tau, t, u, p, mode=mode)
+    m.close()
+
+
+EDGE_NU = [2120.0, 2605.0, 1360.0, 1805.0, 820.0, 960.0, 4000.0, np.nextafter(2120.0, 0), np.nextafter(2605.0, 1e9),
+           np.nextafter(1360.0, 0), np.nextafter(1805.0, 1e9), np.nextafter(820.0, 1e9), np.nextafter(960.0, 0),
+           np.nextafter(4000.0, 0), 1.0, 2362.5, 1582.5, 890.0, 667.782]
+
+
+def test_continua_on_the_window_edges(hip, oracle):
+    """Every continuum at channels exactly on / one ulp beside its window edges (jr_common.h:318, 345, 367, 381)."""
+    n = 4096
+    rng = np.random.default_rng(1)
+    p = 10.0 ** rng.uniform(-2, 3.05, n)
+    t = np.concatenate([[100.0, 399.99, 230.0, 260.0, 296.0, 273.0], rng.uniform(160, 330, n - 6)])
+    q = np.concatenate([[0.0, 1.0], 10.0 ** rng.uniform(-7, -1.5, n - 2)])
+    u_co2 = 10.0 ** rng.uniform(10, 24, n)
+    u_h2o = 10.0 ** rng.uniform(10, 24, n)
+    for lo in range(0, len(EDGE_NU), 4):                     # a few channels per model
+        nus = EDGE_NU[lo:lo + 4]
+        case = common.Case(["CO2", "H2O"], nus, os.path.join(common.GOLD, "limb", "atm.tab"), np.zeros((1, 7)),
+                           table_kw=dict(nlev=2, ntemp=2))
+        m = hip.Model(case.ctl, case.lib_tables())
+        for d, nu in enumerate(nus):
+            got = m.kat_continua(d, p, t, q, u_co2, u_h2o)
+            ref = oracle.continua(nu, p, t, q, u_co2, u_h2o)
+            inside = [0 <= nu < 4000, 0 <= nu < 20000, 2120 <= nu <= 2605, 1360 <= nu <= 1805]
+            for k, name in enumerate(("co2", "h2o", "n2", "o2")):
+                assert np.all(np.isfinite(got[k]))
+                if not inside[k]:
+                    assert np.all(got[k] == 0) and np.all(ref[k] == 0), (name, nu)
+                    continue
+                assert np.any(ref[k] != 0), (name, nu)
+                # co2 is arithmetic only (same doubles); the others call exp / tanh / pow of the device library
+                tol = 0.0 if name == "co2" else 4e-15 if name in ("n2", "o2") else 2e-14
+                err = np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1e-300)
+                assert err.max() <= tol, (name, nu, err.max())
+        m.close()
+
+
+def test_source_function_update_gate_surface_and_brightness(hip, oracle):
+    case = common.nadir_case()                               # 3 channels, WRITE_BBT = 1
+    m = hip.Model(case.ctl, case.lib_tables())
+    ot = case.oracle_tables(oracle)
+    rng = np.random.default_rng(2)
+    gate = around(1e-50, 3) + [0.0, 1e-60, 1e-49, 1e-300, 1.0, 0.3]
+    n = 3000
+    t = np.concatenate([[100.0, 100.25, 399.99, 399.75, 250.0, 250.125], rng.uniform(100.0, 399.99, n - 6)])
+    tau_gas = np.concatenate([gate, 10.0 ** rng.uniform(-60, 0, n - len(gate))])
+    beta = np.concatenate([[0.0, 700.0, 1e-300], 10.0 ** rng.uniform(-12, 2, n - 3)])
+    rad0, tau0 = rng.uniform(0, 1e-3, n), rng.uniform(0, 1, n)
+    for d in range(3):
+        rad, tau, src = m.kat_update(d, 0, t, tau_gas, beta, rad0, tau0)
+        rrad, rtau, rsrc = oracle.new_obs(ot, d, t, tau_gas, beta, rad0, tau0)
+        assert same_doubles(src, rsrc)                                               # interpolation: same doubles
+        closed = tau_gas <= 1e-50                                                    # gate shut: nothing changes
+        assert np.any(closed) and np.array_equal(rad[closed], rad0[closed]) and np.array_equal(tau[closed], tau0[closed])
+        assert np.array_equal(rrad[closed], rad0[closed]) and np.array_equal(rtau[closed], tau0[closed])
+        # exp of the device library differs from libm's in the last place: eps = 1 - tau_gas exp(-beta) moves by ~1e-16
+        assert np.all(np.abs(rad - rrad) <= 4e-16 * (np.abs(rrad) + rsrc))
+        assert np.abs(tau - rtau).max() <= 4e-16
+        # epilogue: surface term for tsurf > 0 (-999 = no ground hit), brightness temperature where asked
+        tsurf = np.where(rng.uniform(size=n) < 0.5, t, -999.0)
+        bbt = (rng.uniform(size=n) < 0.5).astype(np.float64)
+        rad_e, _, _ = m.kat_update(d, 1, tsurf, bbt, np.zeros(n), rad0 + 1e-6, tau0)
+        ref_e = oracle.epilogue(ot, d, case.ctl.nu[d], tsurf, bbt, rad0 + 1e-6, tau0)
+        plain = bbt == 0
+        assert same_doubles(rad_e[plain], ref_e[plain])                              # surface term: same doubles
+        assert np.abs(rad_e[~plain] / ref_e[~plain] - 1).max() < 1e-14               # log1p of the device library
+    m.close()

@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "jurassic-gpu_amd"), os.path.join(ROOT,
 import numpy as np
 import bench
 from jurassic_hip import lib
-case = bench.build_case("limb_1e6", 1_000_000, 1000)
+case = bench.build_case("limb_1e6", bench.global_geometry("limb_1e6", 1_000_000, 1000))
 m = lib.Model(case.ctl, case.lib_tables())
 m.set_atm(case.atm)
 m.formod_host(case.geom[:1000])

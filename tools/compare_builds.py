@@ -12,7 +12,7 @@ if sys.argv[1] == "--dump":
     from jurassic_hip import lib
     out = {}
     for workload, n in (("limb_1e6", int(sys.argv[3])), ("nadir_1e5", 100_000)):
-        case = bench.build_case(workload, n, 1000)
+        case = bench.build_case(workload, bench.global_geometry(workload, n, 1000))
         m = lib.Model(case.ctl, case.lib_tables())
         m.set_atm(case.atm)
         r = m.formod_host(case.geom)

@@ -14,7 +14,7 @@ from jurassic_hip import lib
 
 out = {}
 for workload, n in (("limb_1e6", int(sys.argv[1]) if len(sys.argv) > 1 else 300_000), ("nadir_1e5", 100_000)):
-    case = bench.build_case(workload, n, 1000)
+    case = bench.build_case(workload, bench.global_geometry(workload, n, 1000))
     m = lib.Model(case.ctl, case.lib_tables())
     m.set_atm(case.atm)
     os.environ.pop("JUR_EGA_NO_RCP", None)
