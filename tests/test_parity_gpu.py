@@ -404,6 +404,51 @@ def test_drop_in_nadir_in_fresh_process(hip, oracle, tmp_path):
     assert out.returncode == 0 and "DROPIN_NADIR_OK" in out.stdout, out.stdout + out.stderr
 
 
+DROPIN_TOGGLE = r"""
+import os, sys
+sys.path[:0] = [{root!r}, os.path.join({root!r}, 'jurassic-gpu_amd'), os.path.join({root!r}, 'tests')]
+import numpy as np, common
+from oracle import orc
+from jurassic_hip import abi, lib, synth, textio
+geom = synth.limb_geometry(200, seed=9)
+case = common.limb_case(geom=geom, nu=common.CTM4_NU, ctm_auto=1, ctm_co2=0, ctm_h2o=0, ctm_n2=0, ctm_o2=0, useGPU=1)
+case.write_files({tmp!r}, base='tog')
+tb = orc.Tables(case.ctl.ng, case.ctl.nd); assert tb.read_ascii(case.ctl) == 0 and tb.planck_filt(case.ctl) == 0
+
+def both():
+    obs, ref = abi.obs_t(), abi.obs_t()
+    for o in (obs, ref):
+        o.nr = len(geom)
+        for c, name in enumerate(textio.OBS_COLS[:7]):
+            np.ctypeslib.as_array(getattr(o, name))[:o.nr] = geom[:, c]
+    lib.formod(case.ctl, case.atm, obs)
+    orc.formod(case.ctl, case.atm, ref, tb)
+    a, b = np.ctypeslib.as_array(obs.rad)[:len(geom), :4].copy(), np.ctypeslib.as_array(ref.rad)[:len(geom), :4].copy()
+    assert np.max(np.abs(a - b) / np.abs(b)) < 1e-9, np.max(np.abs(a - b) / np.abs(b))
+    return a
+
+off = both()                                    # first call of the process: every continuum switched off
+case.ctl.ctm_h2o = 1                            # switched on later: looked up then (CPUdrivers.c:126-128)
+h2o = both()
+case.ctl.ctm_co2 = 1; case.ctl.ctm_n2 = 1; case.ctl.ctm_o2 = 1
+allon = both()
+assert np.any(np.abs(h2o - off) > 1e-6 * off)                         # the H2O continuum did arrive
+assert np.any(np.abs(allon[:, 3] - h2o[:, 3]) > 1e-6 * h2o[:, 3])     # N2 window at 2150 cm^-1
+case.ctl.ctm_h2o = 0; case.ctl.ctm_co2 = 0; case.ctl.ctm_n2 = 0; case.ctl.ctm_o2 = 0
+assert np.array_equal(both(), off)                                     # and off again
+print('TOGGLE_OK')
+"""
+
+
+def test_drop_in_continuum_switches_toggle_between_calls(hip, oracle, tmp_path):
+    """Run-time switches are honoured on every drop-in call; a continuum that is off in the FIRST call of the
+    process and on in a later one finds its emitter then, as upstream's latched statics do (CPUdrivers.c:126-134)."""
+    script = tmp_path / "toggle.py"
+    script.write_text(DROPIN_TOGGLE.format(root=common.ROOT, tmp=str(tmp_path)))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "TOGGLE_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 def test_model_from_files_uses_the_binary_cache(hip, oracle, tmp_path, monkeypatch):
     """READ_BINARY=-1 / WRITE_BINARY=1 (upstream defaults, jurassic.c:1018-1019): the first model parses
     the ASCII tables and writes the cache into the working directory, the second one is built from the
@@ -600,6 +645,132 @@ def test_large_batch_properties(hip, oracle):
     assert np.array_equal(a["np"][idx], ref["np"])
     assert common.rel_err(a["rad"][idx], ref["rad"]).max() < RTOL
     assert common.rel_err(a["tau"][idx], ref["tau"]).max() < RTOL
+    model.close()
+
+
+def test_nadir_1e5_properties(hip, oracle):
+    """BASELINE configs[1] at full size (1e5 nadir observations, CO2, the three AIRS channels of example/nadir,
+    brightness temperatures, every ray ends on the ground): properties that need no oracle run at that size,
+    plus a sampled oracle comparison."""
+    nr = 100_000
+    geom = synth.nadir_geometry(nr, seed=1000)
+    case = common.nadir_case(geom=geom[:8])
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    a = model.formod_host(geom)
+    assert np.isfinite(a["rad"]).all() and np.all((a["tau"] >= 0) & (a["tau"] <= 1))
+    assert np.all((a["rad"] > 150) & (a["rad"] < 320))                  # brightness temperatures [K]
+    assert set(np.unique(a["np"])) <= {181, 182}                         # SURVEY section 6: 181-182 points per nadir ray
+    model.set_chunk_rays(7040)                                           # independence of the chunking: bit-identical
+    b = model.formod_host(geom)
+    for k in ("rad", "tau", "tp", "np"):
+        assert np.array_equal(a[k], b[k]), k
+    model.set_sort_rays(False)                                           # ... and of the processing order
+    c = model.formod_host(geom)
+    assert np.array_equal(a["rad"], c["rad"]) and np.array_equal(a["tau"], c["tau"])
+    perm = np.random.default_rng(0).permutation(nr)[:30_000]             # rays are independent
+    d = model.formod_host(geom[perm])
+    assert np.array_equal(d["rad"], a["rad"][perm]) and np.array_equal(d["tau"], a["tau"][perm])
+    idx = np.random.default_rng(1).choice(nr, 3000, replace=False)
+    ref = oracle.formod_rays(case.ctl, case.atm, case.oracle_tables(oracle), geom[idx])
+    assert np.array_equal(a["np"][idx], ref["np"])
+    assert common.rel_err(a["rad"][idx], ref["rad"]).max() < RTOL
+    assert np.all(np.abs(a["tau"][idx] - ref["tau"]) <= RTOL * np.abs(ref["tau"]) + 1e-13)
+    model.close()
+
+
+WIDE_FULL = r"""
+import os, sys, time
+sys.path[:0] = [{root!r}, os.path.join({root!r}, 'jurassic-gpu_amd'), os.path.join({root!r}, 'tests')]
+import numpy as np, common
+from oracle import orc
+from jurassic_hip import abi, lib, synth, textio
+import bench
+assert (abi.ND, abi.NG) == (2378, 3)
+nr = {nr}
+nu = [650.0 + i * (2665.0 - 650.0) / 2377 for i in range(2378)]           # SURVEY 8d, C5
+em = ["CO2", "H2O", "O3"]
+ctl = abi.make_ctl(em, nu)
+atm = textio.read_atm(os.path.join(common.GOLD, "limb", "atm.tab"), ctl)
+geom = synth.nadir_geometry(nr, seed=7)
+# full-size tables, 33 p x 10 T x ~203 u per pair: 7134 tables, 4.8e8 entries (3.8 GB on the device) -- every row
+# goes to the library and to the oracle as it is generated, nothing is kept
+tb, ot = lib.Tables(3, 2378), orc.Tables(3, 2378)
+t0 = time.time()
+for g, e in enumerate(em):
+    for d, v in enumerate(nu):
+        rows = synth.table_rows(e, v, id_=d % 7)
+        tb.feed_rows(g, d, rows)
+        ot.feed_rows(g, d, rows)
+        if g == 0:
+            x, f = synth.boxcar_filter(v)
+            tb.set_filter(d, x, f)
+            ot.planck_shape(d, x, f)
+assert tb.entries() > 4.5e8
+model = lib.Model(ctl, tb)
+model.set_atm(atm)
+a = model.formod_host(geom)
+assert np.isfinite(a["rad"]).all() and np.all(a["rad"] > 0) and np.all((a["tau"] >= 0) & (a["tau"] <= 1))
+assert set(np.unique(a["np"])) <= {{181, 182}}
+model.set_chunk_rays(448)                                                  # chunking: bit-identical
+b = model.formod_host(geom)
+for k in ("rad", "tau", "tp", "np"):
+    assert np.array_equal(a[k], b[k]), k
+perm = np.random.default_rng(0).permutation(nr)[:512]                      # rays are independent
+c = model.formod_host(geom[perm])
+assert np.array_equal(c["rad"], a["rad"][perm]) and np.array_equal(c["tau"], a["tau"][perm])
+idx = np.random.default_rng(1).choice(nr, 16, replace=False)               # sampled rows against the oracle
+orc.set_threads(bench.usable_cores())
+ref = orc.formod_rays(ctl, atm, ot, geom[idx])
+assert np.array_equal(a["np"][idx], ref["np"])
+assert np.max(np.abs(a["rad"][idx] - ref["rad"]) / np.abs(ref["rad"])) < 1e-9
+assert np.all(np.abs(a["tau"][idx] - ref["tau"]) <= 1e-9 * np.abs(ref["tau"]) + 1e-13)
+print('WIDE_FULL_OK', a["rad"].shape, tb.entries(), '%.0f s' % (time.time() - t0))
+"""
+
+
+def test_2378_channels_full_size_tables(hip, oracle, tmp_path):
+    """BASELINE configs[4] on one GPU at the size the wide benchmark runs (tools/bench_wide.py): 2048 nadir
+    observations x 2378 channels x 3 emitters with FULL-size tables (3.8 GB: beyond L2 and Infinity Cache),
+    the property checks of the other bench-size tests plus sampled oracle rows.  Own process: the ND=2378 build."""
+    script = tmp_path / "wide_full.py"
+    script.write_text(WIDE_FULL.format(root=common.ROOT, nr=2048))
+    env = dict(os.environ, JUR_ND="2378", JUR_NG="3", JUR_SUFFIX="_nd2378")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0 and "WIDE_FULL_OK (2048, 2378)" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_host_entry_with_pinned_and_pageable_arrays(hip):
+    """jur_formod_host above the package size: arrays in pinned memory (jur_host_alloc) travel in place, pageable
+    ones through the model's pinned image, copies overlapped with the kernels on a second stream -- same bits as
+    the device-pointer entry either way, NaN mask included."""
+    nr = 150_000
+    case = common.limb_case(geom=synth.limb_geometry(nr, seed=31, nprofiles=4), nu=common.CTM4_NU, nprofiles=4)
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    base = model.formod_host(case.geom[:60_000])                        # package-sized path (one staged transfer)
+    res = {}
+    for pinned in (True, False):
+        b = model.host_buffers(nr, pinned=pinned)
+        b.set_geometry(case.geom)
+        b.rad[:] = 0.0
+        b.rad[5, 1] = np.nan
+        b.rad[nr - 1, 3] = np.inf
+        model.formod_host_buffers(b)
+        res[pinned] = dict(rad=b.rad.copy(), tau=b.tau.copy(), tp=b.tp.T.copy(), np=b.np.copy())
+        b.rad[:] = 0.0
+        model.formod_host_buffers(b)                                     # reuse of the staging buffers
+        keep = np.ones(nr, bool); keep[[5, nr - 1]] = False
+        assert np.array_equal(b.rad[keep], res[pinned]["rad"][keep]) and np.isfinite(b.rad).all()
+        b.close()
+    for k in ("rad", "tau", "tp", "np"):
+        assert np.array_equal(res[True][k], res[False][k], equal_nan=(k == "rad")), k
+    r = res[True]
+    assert np.isnan(r["rad"][5, 1]) and np.isnan(r["rad"][nr - 1, 3]) and np.isnan(r["rad"]).sum() == 2
+    for k in ("rad", "tau", "tp", "np"):
+        x, y = r[k][:60_000], base[k]
+        m = np.isfinite(x) if k == "rad" else np.ones(x.shape, bool)
+        assert np.array_equal(x[m], y[m]), k
     model.close()
 
 

@@ -16,7 +16,7 @@ import re, struct, sys, hashlib
 from pathlib import Path
 
 REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference/src")
-OUT = Path(__file__).resolve().parent.parent / "jurassic-gpu_amd" / "data" / "clim.bin"
+OUT = Path(sys.argv[2]) if len(sys.argv) > 2 else Path(__file__).resolve().parent.parent / "jurassic-gpu_amd" / "data" / "clim.bin"
 
 txt = (REF / "climatology.tbl").read_text()
 blob = b""

@@ -18,7 +18,7 @@ import re, struct, sys, hashlib
 from pathlib import Path
 
 REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference/src")
-OUT = Path(__file__).resolve().parent.parent / "jurassic-gpu_amd" / "data" / "ctm.bin"
+OUT = Path(sys.argv[2]) if len(sys.argv) > 2 else Path(__file__).resolve().parent.parent / "jurassic-gpu_amd" / "data" / "ctm.bin"
 
 def arrays(fname):
     txt = (REF / fname).read_text()
