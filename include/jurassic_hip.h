@@ -162,11 +162,20 @@ int  jur_model_set_trace_multiple(jur_model_t *m, int mult);
  * transmittances); the rays-per-chunk shrink to fit.  Default 128 GiB of the 288 GB. */
 int  jur_model_set_workspace_budget(jur_model_t *m, long bytes);
 
+/* Calls of up to max_rays rays (default 4096; 0: never) run as ONE fused kernel -- ray tracing, emissivity growth
+ * and radiance update of a ray as producer/consumer wavefronts of one workgroup, the line of sight handed on through
+ * LDS -- instead of the three batched kernels: the sizes the reference's callers use (packages of <= NR rays).
+ * rays_per_group: rays per workgroup, 0 = chosen from the call size.  Configurations with more (channel, gas)
+ * chains per ray than the LDS rings hold use the batched kernels whatever the size.  Same results bit for bit. */
+int  jur_model_set_pencil(jur_model_t *m, long max_rays, int rays_per_group);
+
 /* Summed duration in ms and launch count of each kernel since the last query,
  * measured with HIP events on the launch stream while timing is enabled:
  * [0] jur_trace_kernel, [1] jur_ega_kernel, [2] jur_combine_kernel. */
 int  jur_model_enable_timing(jur_model_t *m, int on);
 int  jur_model_last_kernel_ms(jur_model_t *m, double out_ms[3], long out_launches[3]);
+/* ... and of the fused kernel (call jur_model_last_kernel_ms first) */
+int  jur_model_last_pencil_ms(jur_model_t *m, double *out_ms, long *out_launches);
 
 /* ---- known-answer hooks (for tests; not on the product path) -------------------------------------------
  * The device functions of the path evaluated on host arrays of n inputs, one element per lane, so that each can be

@@ -101,6 +101,10 @@ long jurk_sort_tmp_bytes(long nr);
 int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, double const *d_geom, int *d_order, void *tmp,
                    long tmp_bytes, void *stream);
 
+/* the whole path of small calls in one kernel, RB rays per workgroup (c->order is ignored: nothing is sorted) */
+long jurk_pencil_lds_bytes(jur_view_t const *v, int RB);
+int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int RB, void *stream);
+
 /* known-answer hooks (tests): device functions on arrays, see jurassic_hip.h */
 int jurk_kat_ega(jur_view_t const *v, int g, int d, long n, double const *tau, double const *t, double const *u, double const *p,
                  int mode, int chain, double *out, void *stream);

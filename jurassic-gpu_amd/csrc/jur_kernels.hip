@@ -209,10 +209,6 @@ __device__ __attribute__((noinline)) ClipOut clip_exit(double px0, double px1, d
   return {xh[0] + frac * (x0 - xh[0]), xh[1] + frac * (x1 - xh[1]), xh[2] + frac * (x2 - xh[2]), frac};
 }
 
-// 4 waves per SIMD (128 VGPRs, some scratch): measured 20 % faster than 2 waves without spills once a
-// launch carries enough rays (>= 4 x 131072) to fill them
-__global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chunk_t c) {
-  __shared__ double tr_sh[15][64];
 #define TR_PZ tr_sh[0][threadIdx.x]
 #define TR_PX(i) tr_sh[1 + (i)][threadIdx.x]
 #define TR_LZ0 tr_sh[4][threadIdx.x]
@@ -222,16 +218,24 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
 #define TR_LZ2 tr_sh[10][threadIdx.x]
 #define TR_LX2(i) tr_sh[11 + (i)][threadIdx.x]
 #define TR_LDS2 tr_sh[14][threadIdx.x]
-  int const r = blockIdx.x * blockDim.x + threadIdx.x;   // slot in the chunk
-  if (r >= c.n) return;
-  long const ray = c.order ? (long)c.order[r] : c.first + r;
-  size_t const R = (size_t)c.stride;
-  double *const los = c.los;
-  auto F = [&](int field, int ip) -> double & { return los[((size_t)field * NLOS + ip) * R + r]; };
-  int const f_k = JUR_F_K, f_u = JUR_F_K + v.nw;
+// One line of sight (traceray, jr_common.h:585-711, with tangent_point :502-539, trapezoid_rule_pos :437-443 and
+// column_density :446-453 folded in), one lane per ray.  L says where the LOS fields of a point live -- the HBM
+// workspace of the batched kernels, or a ring in LDS in the fused kernel -- through
+//   L.at(field, point)      reference to the field's slot
+//   L.field_stride()        distance between the slots of consecutive fields (the emitters' columns are consecutive)
+//   L.begin_point(i)        called before point i is first written
+//   L.points_final(i)       called when points 0 .. i-1 will not change any more (point i still may: the exit
+//                           clipping rewrites the point before the exit, jr_common.h:645-646)
+//   L.ray_final(n, tsurf)   called when the ray has left the atmosphere with n points (not for a ray that runs into
+//                           the NLOS limit: see the returned np)
+// tr_sh: the per-lane tangent-point bookkeeping in LDS, column threadIdx.x.
+struct TraceResult { int np; double tsurf, tpz, tplon, tplat; };
 
-  double const time = c.geom[0][ray], obsz = c.geom[1][ray], obslon = c.geom[2][ray], obslat = c.geom[3][ray],
-               vpz = c.geom[4][ray], vplon = c.geom[5][ray], vplat = c.geom[6][ray];
+template <class Los>
+__device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double const time, double const obsz, double const obslon,
+                                                 double const obslat, double const vpz, double const vplon, double const vplat,
+                                                 Los &L, double (&tr_sh)[15][64], int *status) {
+  int const f_k = JUR_F_K, f_u = JUR_F_K + v.nw;
   double tsurf = -999;
   double tpz = vpz, tplon = vplon, tplat = vplat;
   int np = 0;
@@ -313,6 +317,7 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
     for (; np < NLOS; ++np) {
       // the bookkeeping written to LDS is to be read back from there, not kept in registers as well
       asm volatile("" ::: "memory");
+      L.begin_point(np);                  // (fused kernel: the ring slot of this point must be free)
       double ds = v.rayds;
       double const dz = v.raydz;
       if (dz > 0.) {
@@ -334,9 +339,9 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
           if (low_idx == np - 1) TR_LDS1 = dsp;
           if (low_idx + 1 == np - 1) TR_LDS2 = dsp;
           double const dsn = (np >= 2) ? 0.5 * (ds_pp + dsp) : dsp * 0.5;
-          F(JUR_F_DS, np - 1) = dsn;
-          redo_columns(v.atm_z, v.atm_q, v.atm_np, atm0, atmn, v.ng, TR_PZ, F(JUR_F_P, np - 1), F(JUR_F_T, np - 1), dsn,
-                       &F(f_u, np - 1), (size_t)NLOS * R);
+          L.at(JUR_F_DS, np - 1) = dsn;
+          redo_columns(v.atm_z, v.atm_q, v.atm_np, atm0, atmn, v.ng, TR_PZ, L.at(JUR_F_P, np - 1), L.at(JUR_F_T, np - 1), dsn,
+                       &L.at(f_u, np - 1), L.field_stride());
           ds_p = dsp;
         }
         ds = 0.;
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
       double p, t, rdz = 0;
       int const ia = intpol_pt<true>(v, atm0, atmn, z, p, t, zdir, zhint, &rdz);
       double const dsn = (np >= 1) ? 0.5 * (ds_p + ds) : ds * 0.5;   // redone for the point before the exit
-      F(JUR_F_DS, np) = dsn;
+      L.at(JUR_F_DS, np) = dsn;
       {  // remaining quantities on the same bracket (jr_common.h:557-567)
         double const za = v.atm_z[ia], zb = v.atm_z[ia + 1];
         double const kt = JUR_BOLTZMANN * t, rkt = 1. / kt;   // one division for all emitters' columns (div_rcp)
@@ -353,17 +358,17 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
           double const *q = v.atm_q + (size_t)ig * v.atm_np;
           double qv;
           if (zdir) qv = lip_rcp(za, q[ia], zb, q[ia + 1], z, rdz); else qv = lip(za, q[ia], zb, q[ia + 1], z);
-          F(f_u + ig, np) = div_rcp(10. * qv * p, kt, rkt) * dsn;
-          if (ig == v.ig_h2o) F(JUR_F_QH2O, np) = qv;
+          L.at(f_u + ig, np) = div_rcp(10. * qv * p, kt, rkt) * dsn;
+          if (ig == v.ig_h2o) L.at(JUR_F_QH2O, np) = qv;
         }
         for (int iw = 0; iw < v.nw; iw++) {
           double const *k = v.atm_k + (size_t)iw * v.atm_np;
-          if (zdir) F(f_k + iw, np) = lip_rcp(za, k[ia], zb, k[ia + 1], z, rdz);
-          else F(f_k + iw, np) = lip(za, k[ia], zb, k[ia + 1], z);
+          if (zdir) L.at(f_k + iw, np) = lip_rcp(za, k[ia], zb, k[ia + 1], z, rdz);
+          else L.at(f_k + iw, np) = lip(za, k[ia], zb, k[ia + 1], z);
         }
       }
-      F(JUR_F_P, np) = p;
-      F(JUR_F_T, np) = t;
+      L.at(JUR_F_P, np) = p;
+      L.at(JUR_F_T, np) = t;
       ds_pp = ds_p; ds_p = ds;
 
       if (low_idx >= 0 && low_idx == np - 1) { TR_LZ2 = z; TR_LDS2 = ds; for (int i = 0; i < 3; i++) TR_LX2(i) = x[i]; }
@@ -379,8 +384,10 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
 
       if (stop) {
         tsurf = (stop == 2 ? t : -999);
+        L.ray_final(np + 1, tsurf);       // (fused kernel: this ray has np + 1 points, all of them final)
         break;
       }
+      L.points_final(np);                 // (fused kernel: points 0 .. np-1 of this ray will not change any more)
 
       double n = 1., ngr[3] = {0., 0., 0.};
       if (v.refrac && z <= 60.) {  // refractivity gradient by finite differences (:665-681)
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
     }
     ++np;
     if (NLOS <= np) {  // the reference aborts here (jr_common.h:693-695); flag and clamp
-      atomicOr(c.status, 1);
+      atomicOr(status, 1);
       np = NLOS - 1;
     }
 
@@ -458,12 +465,37 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
 
   }
 
-  c.np[r] = np;
-  c.tsurf[r] = tsurf;
-  if (c.np_out) c.np_out[ray] = np;
-  c.tp[0][ray] = tpz;
-  c.tp[1][ray] = tplon;
-  c.tp[2][ray] = tplat;
+  return {np, tsurf, tpz, tplon, tplat};
+}
+
+// LOS fields in the HBM workspace, [field][point][ray slot]
+struct LosWorkspace {
+  double *los;
+  size_t R;
+  int r;
+  __device__ __forceinline__ double &at(int field, int ip) const { return los[((size_t)field * NLOS + ip) * R + r]; }
+  __device__ __forceinline__ size_t field_stride() const { return (size_t)NLOS * R; }
+  __device__ __forceinline__ void begin_point(int) const {}
+  __device__ __forceinline__ void points_final(int) const {}
+  __device__ __forceinline__ void ray_final(int, double) const {}
+};
+
+// 4 waves per SIMD (128 VGPRs, some scratch): measured 20 % faster than 2 waves without spills once a
+// launch carries enough rays (>= 4 x 131072) to fill them
+__global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chunk_t c) {
+  __shared__ double tr_sh[15][64];
+  int const r = blockIdx.x * blockDim.x + threadIdx.x;   // slot in the chunk
+  if (r >= c.n) return;
+  long const ray = c.order ? (long)c.order[r] : c.first + r;
+  LosWorkspace L{c.los, (size_t)c.stride, r};
+  TraceResult const t = trace_ray(v, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray], c.geom[4][ray],
+                                  c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
+  c.np[r] = t.np;
+  c.tsurf[r] = t.tsurf;
+  if (c.np_out) c.np_out[ray] = t.np;
+  c.tp[0][ray] = t.tpz;
+  c.tp[1][ray] = t.tplon;
+  c.tp[2][ray] = t.tplat;
 }
 
 #undef TR_PZ
@@ -931,6 +963,214 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
 }
 
 // ---------------------------------------------------------------------------------------
+// jur_pencil_kernel: the whole path of a ray pencil inside ONE workgroup -- for calls of the size the
+// reference's callers make (packages of <= NR = 1088 rays, formod.c:100, kernel() jurassic.c:844), which cannot
+// fill 256 CUs with one lane per ray and would run the three batched kernels as three serial <= 400-step chains.
+//
+// A workgroup owns RB rays.  Its wavefronts take roles and hand the line of sight from one to the next through
+// LDS, point by point, as it is being traced:
+//   wave 0              traces the rays, one lane each (trace_ray), into a ring of LOS points in LDS;
+//   waves 1 .. NE       one lane per (ray, channel, gas) chain: the emissivity-growth recurrence of the points the
+//                       tracer has released, search state and accumulated transmittance of the chain in LDS;
+//                       segment transmittances go to a second ring;
+//   waves NE+1 .. +NC   one lane per (ray, channel): continua, product over the gases, Planck source, radiance
+//                       update, epilogue -- the body of jur_combine_kernel.
+// The roles overlap along the ray: a call takes about as long as its longest ray takes to TRACE, the LOS state
+// and the segment transmittances never touch HBM, and nothing is sorted.  Same device functions, same operand
+// order, same doubles as the batched kernels (tests compare the two paths bit for bit).
+//
+// Hand-over: cnt_trace = number of points of every still-running ray that will not change any more (the lanes of
+// wave 0 step in lockstep), npr[ray] = 1 + its point count once the ray has left the atmosphere; every consumer wave
+// publishes the number of points it has finished.  All counters live in LDS, release/acquire at workgroup scope.
+// Every wait is for a wave of the same workgroup that is resident and never waits for the waiter in turn
+// (tracer <- combine: ring slot free; ega <- tracer: point released, <- combine: eps slot free; combine <- ega),
+// so every wave reaches its exit.
+// ---------------------------------------------------------------------------------------
+#define PEN_RING 16       // LOS points in flight (power of two)
+#define PEN_RINGE 8       // segment transmittances in flight (power of two, <= PEN_RING)
+#define PEN_MAXE 8        // at most this many ega / combine waves per workgroup
+#define PEN_MAXC 4
+
+struct PenCtl {            // LDS, one per workgroup
+  int cnt_trace, done;
+  int cnt_ega[PEN_MAXE];
+  int cnt_comb[PEN_MAXC];
+};
+
+__device__ __forceinline__ int ld_acq(int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_rel(int *p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int min_cnt(int *p, int n) {
+  int m = ld_acq(p);
+  for (int i = 1; i < n; i++) m = min(m, ld_acq(p + i));
+  return m;
+}
+__device__ __forceinline__ bool first_active_lane() {
+  return (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1;
+}
+
+// LOS fields of the workgroup's rays in the LDS ring [point % PEN_RING][field][ray]
+struct LosRing {
+  double *ring;
+  PenCtl *ctl;
+  int *npr;
+  double *tsurf;
+  int nfield, RB, r, nc;
+  __device__ __forceinline__ double &at(int field, int ip) const { return ring[((ip & (PEN_RING - 1)) * nfield + field) * RB + r]; }
+  __device__ __forceinline__ size_t field_stride() const { return (size_t)RB; }
+  __device__ __forceinline__ void begin_point(int ip) const {   // the slot still holds point ip - PEN_RING
+    if (ip >= PEN_RING)
+      while (min_cnt(ctl->cnt_comb, nc) + PEN_RING <= ip) __builtin_amdgcn_s_sleep(2);
+  }
+  __device__ __forceinline__ void points_final(int np) const {
+    if (first_active_lane()) st_rel(&ctl->cnt_trace, np);
+  }
+  __device__ __forceinline__ void ray_final(int n, double ts) const {
+    tsurf[r] = ts;
+    st_rel(&npr[r], n + 1);
+  }
+};
+
+// wait until point ip is released (returns the released count c > ip) or the tracer is through (returns its final
+// count, possibly <= ip: no such point)
+__device__ __forceinline__ int wait_point(PenCtl *ctl, int ip) {
+  for (;;) {
+    int c = ld_acq(&ctl->cnt_trace);
+    if (c > ip) return c;
+    if (ld_acq(&ctl->done)) return ld_acq(&ctl->cnt_trace);
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+template <bool WARM>
+__global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chunk_t c, int RB, int NE, int NC) {
+  __shared__ double tr_sh[15][64];
+  __shared__ PenCtl ctl;
+  int const nd = v.nd, ng = v.ng, npair = nd * ng, nfield = JUR_F_K + v.nw + ng;
+  int const nchain = RB * npair, nitem = RB * nd;
+  // dynamic LDS: rings, chain state, per-(ray, channel) radiance state, per-ray results of the tracer
+  double *const ring = reinterpret_cast<double *>(jur_lds);
+  double *const epsr = ring + (size_t)PEN_RING * nfield * RB;
+  double *const st_tau = epsr + (size_t)PEN_RINGE * (npair > 0 ? npair : 1) * RB;
+  double *const c_rad = st_tau + (nchain > 0 ? nchain : 1);
+  double *const c_tau = c_rad + nitem;
+  double *const tsurf = c_tau + nitem;
+  unsigned *const st_br = reinterpret_cast<unsigned *>(tsurf + RB);
+  unsigned *const st_ia = st_br + (nchain > 0 ? nchain : 1);
+  unsigned *const st_ib = st_ia + (nchain > 0 ? nchain : 1);
+  int *const npr = reinterpret_cast<int *>(st_ib + (nchain > 0 ? nchain : 1));
+  int const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  long const ray0 = (long)blockIdx.x * RB;                         // first slot of this workgroup
+  int const nray = (int)((c.n - ray0 < RB) ? c.n - ray0 : RB);    // rays it really has
+
+  for (int i = tid; i < nchain; i += blockDim.x) { st_tau[i] = 1.0; st_br[i] = 0; st_ia[i] = 0; st_ib[i] = 0; }
+  for (int i = tid; i < nitem; i += blockDim.x) { c_rad[i] = 0.0; c_tau[i] = 1.0; }
+  for (int i = tid; i < RB; i += blockDim.x) { npr[i] = (i < nray) ? 0 : 1; tsurf[i] = -999; }   // 1: through, no points
+  if (tid == 0) {
+    ctl.cnt_trace = 0; ctl.done = 0;
+    for (int i = 0; i < PEN_MAXE; i++) ctl.cnt_ega[i] = 0;
+    for (int i = 0; i < PEN_MAXC; i++) ctl.cnt_comb[i] = 0;
+  }
+  __syncthreads();
+
+  if (wave == 0) {
+    // ---- tracer ----
+    if (lane < nray) {
+      long const ray = c.first + ray0 + lane;
+      LosRing L{ring, &ctl, npr, tsurf, nfield, RB, lane, NC};
+      TraceResult const t = trace_ray(v, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray], c.geom[4][ray],
+                                      c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
+      if (c.np_out) c.np_out[ray] = t.np;
+      c.tp[0][ray] = t.tpz;
+      c.tp[1][ray] = t.tplon;
+      c.tp[2][ray] = t.tplat;
+      tsurf[lane] = t.tsurf;
+      st_rel(&npr[lane], t.np + 1);          // also the rays that never entered the atmosphere or ran into NLOS
+    }
+    if (lane == 0) {                         // every ray is through: its point count governs from here on
+      int m = 0;
+      for (int i = 0; i < nray; i++) m = max(m, ld_acq(&npr[i]) - 1);
+      st_rel(&ctl.cnt_trace, m);
+      st_rel(&ctl.done, 1);
+    }
+  } else if (wave <= NE) {
+    // ---- emissivity growth: one chain per (ray, channel, gas) ----
+    int const w = wave - 1, nl = NE * 64, me = w * 64 + lane;
+    PairDesc<false> D{v.lvl, v.crv, 0u, 0u, 0u, 0u};
+    for (int ip = 0;; ++ip) {
+      int const cnt = wait_point(&ctl, ip);
+      if (cnt <= ip) break;
+      if (ip >= PEN_RINGE)
+        while (min_cnt(ctl.cnt_comb, NC) + PEN_RINGE <= ip) __builtin_amdgcn_s_sleep(2);
+      double const *const slot = ring + (size_t)(ip & (PEN_RING - 1)) * nfield * RB;
+      double *const eslot = epsr + (size_t)(ip & (PEN_RINGE - 1)) * npair * RB;
+      for (int e = me; e < nchain; e += nl) {
+        int const pr = e / RB, r = e - pr * RB, d = pr / ng, g = pr - d * ng;
+        int const n1 = ld_acq(&npr[r]);
+        if (n1 ? (ip >= n1 - 1) : (ip >= cnt)) continue;          // this ray has no such point
+        jur_int2 const pd = v.pair[g * nd + d];
+        if (pd.a < 2) continue;                                    // no table: the combine role knows
+        D.l0 = (unsigned)pd.b;
+        double const p = slot[JUR_F_P * RB + r], t = slot[JUR_F_T * RB + r], u = slot[(JUR_F_K + v.nw + g) * RB + r];
+        double const tau_path = st_tau[e];
+        double eps;
+        if constexpr (WARM) {
+          unsigned br = st_br[e], ia = st_ia[e], ib = st_ib[e];
+          eps = ega_eps_warm<false, false>(v, pd, D, tau_path, t, u, p, br, ia, ib);
+          st_br[e] = br; st_ia[e] = ia; st_ib[e] = ib;
+        } else eps = ega_eps_exact<false>(v, pd, D, tau_path, t, u, p);
+        st_tau[e] = tau_path * eps;
+        eslot[pr * RB + r] = eps;
+      }
+      if (first_active_lane()) st_rel(&ctl.cnt_ega[w], ip + 1);
+    }
+  } else {
+    // ---- combine: one lane per (ray, channel) ----
+    int const w = wave - 1 - NE, nl = NC * 64, me = w * 64 + lane;
+    int const f_u = JUR_F_K + v.nw;
+    for (int ip = 0;; ++ip) {
+      int const cnt = wait_point(&ctl, ip);
+      if (cnt <= ip) break;
+      while (min_cnt(ctl.cnt_ega, NE) <= ip) __builtin_amdgcn_s_sleep(2);
+      double const *const slot = ring + (size_t)(ip & (PEN_RING - 1)) * nfield * RB;
+      double const *const eslot = epsr + (size_t)(ip & (PEN_RINGE - 1)) * npair * RB;
+      for (int i = me; i < nitem; i += nl) {
+        int const d = i / RB, r = i - d * RB;
+        int const n1 = ld_acq(&npr[r]);
+        if (n1 ? (ip >= n1 - 1) : (ip >= cnt)) continue;
+        jur_chan_t const ch = v.chan[d];
+        auto L = [&](int field) { return slot[field * RB + r]; };
+        double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
+        double beta_ds = L(JUR_F_K + ch.window) * ds;
+        if ((v.fourbit & 8) && ch.co2_on) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
+        if ((v.fourbit & 4) && ch.h2o_on) beta_ds += ctm_h2o(ch, p, t, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
+        if ((v.fourbit & 2) && ch.n2_on) beta_ds += ctm_n2(ch, p, t) * ds;
+        if ((v.fourbit & 1) && ch.o2_on) beta_ds += ctm_o2(ch, p, t) * ds;
+        double tau_gas = 1.0;
+        for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
+          if (v.pair[g * nd + d].a >= 2) tau_gas *= eslot[(d * ng + g) * RB + r];
+        double rad = c_rad[i], tau = c_tau[i];
+        new_obs_step(tau_gas, beta_ds, planck_src(v.sr + (size_t)d * TBLNS, t), rad, tau);
+        c_rad[i] = rad;
+        c_tau[i] = tau;
+      }
+      if (first_active_lane()) st_rel(&ctl.cnt_comb[w], ip + 1);
+    }
+    for (int i = me; i < nitem; i += nl) {                 // every ray is through (done was seen): epilogue
+      int const d = i / RB, r = i - d * RB;
+      if (r >= nray) continue;
+      size_t const oidx = (size_t)(c.first + ray0 + r) * nd + d;
+      bool const masked = !isfinite(c.rad[oidx]);
+      double rad = c_rad[i];
+      double const tau = c_tau[i];
+      ray_epilogue(v.sr + (size_t)d * TBLNS, v.chan[d].nu, tsurf[r], v.write_bbt, rad, tau);
+      if (masked) rad = __builtin_nan("");
+      c.rad[oidx] = rad;
+      c.tau[oidx] = tau;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Curtis-Godson means along the path (curtis_godson, jr_common.h:455-473; upstream compiles it only
 // with -DCURTIS_GODSON for FORMOD=1 and never consumes the result): per gas, the inclusive prefix
 // sums over the LOS points of u p, u T and u, then cgp = S(u p)/S(u), cgt = S(u T)/S(u), cgu = S(u).
@@ -1199,5 +1439,36 @@ extern "C" int jurk_kat_update(jur_view_t const *v, int d, long n, int what, dou
   if (n <= 0) return 0;
   hipLaunchKernelGGL(jur_kat_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *v, d, n, what,
                      a, b, c, rad, tau, src);
+  return (int)hipGetLastError();
+}
+
+// ---- fused kernel for small calls ----
+// LDS bytes jur_pencil_kernel needs for RB rays per workgroup (0: the configuration does not fit)
+extern "C" long jurk_pencil_lds_bytes(jur_view_t const *v, int RB) {
+  long const npair = (long)v->nd * v->ng, nfield = JUR_F_K + v->nw + v->ng, nchain = RB * npair, nitem = (long)RB * v->nd;
+  long const n1 = nchain > 0 ? nchain : 1;
+  long const bytes = 8 * ((long)PEN_RING * nfield * RB + (long)PEN_RINGE * (npair > 0 ? npair : 1) * RB + n1 + 2 * nitem + RB) +
+                     4 * (3 * n1 + RB) + 64;
+  return bytes <= 96 * 1024 ? bytes : 0;
+}
+
+extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int RB, void *stream) {
+  if (c->n <= 0) return 0;
+  long const lds = jurk_pencil_lds_bytes(v, RB);
+  if (RB < 1 || RB > 64 || lds <= 0) return (int)hipErrorInvalidValue;
+  int const npair = v->nd * v->ng;
+  int NE = (RB * npair + 63) / 64, NC = (RB * v->nd + 63) / 64;
+  NE = NE < 1 ? 1 : (NE > PEN_MAXE ? PEN_MAXE : NE);
+  NC = NC < 1 ? 1 : (NC > PEN_MAXC ? PEN_MAXC : NC);
+  dim3 const grid((unsigned)((c->n + RB - 1) / RB)), block((unsigned)(64 * (1 + NE + NC)));
+  hipStream_t s = (hipStream_t)stream;
+  static bool raised = false;      // dynamic LDS beyond 64 KB needs the attribute once per kernel
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    raised = true;
+  }
+  if (v->sorted_tables) hipLaunchKernelGGL(jur_pencil_kernel<true>, grid, block, (size_t)lds, s, *v, *c, RB, NE, NC);
+  else hipLaunchKernelGGL(jur_pencil_kernel<false>, grid, block, (size_t)lds, s, *v, *c, RB, NE, NC);
   return (int)hipGetLastError();
 }

@@ -70,14 +70,21 @@ struct jur_model {
   int host_call;                /* 1 while jur_formod_host drives jur_formod_device: record / wait for the events above */
   void *last_stream;            /* stream of the last jur_formod_device call (see jur_model_set_atm) */
   int have_last_stream;
+  /* small calls: the fused kernel (jur_pencil_kernel) instead of sort + three batched kernels */
+  long pencil_rays;             /* calls of up to this many rays take it (0: never)             */
+  int pencil_rb;                /* rays per workgroup (0: chosen from the call size)            */
   /* timing */
   int timing;
   hipEvent_t *evpool;           /* 2 events per timed launch                     */
-  unsigned char *evkind;        /* 0 trace, 1 ega, 2 combine                     */
+  unsigned char *evkind;        /* 0 trace, 1 ega, 2 combine, 3 fused (pencil)   */
   int ntimed;
+  double pencil_ms;
+  long pencil_launches;
 };
 
 #define JUR_MAX_TIMED 4096
+
+static int pencil_rays_per_group(jur_model_t const *m, long nr);
 
 static int find_emitter(ctl_t const *ctl, char const *name) {
   for (int ig = 0; ig < ctl->ng; ig++)
@@ -188,6 +195,10 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   m->sort_rays = 1;
   m->ws_budget = 128L << 30;    /* of 288 GB HBM; C3 needs 96 KB per ray */
   m->trace_mult = 1;
+  m->pencil_rays = 4096;
+  m->pencil_rb = 0;
+  if (getenv("JUR_PENCIL_RAYS")) m->pencil_rays = atol(getenv("JUR_PENCIL_RAYS"));
+  if (getenv("JUR_PENCIL_RB")) m->pencil_rb = atoi(getenv("JUR_PENCIL_RB"));
   /* tuning overrides for experiments; the setters of the API do the same */
   if (getenv("JUR_CHUNK_RAYS") && atoi(getenv("JUR_CHUNK_RAYS")) >= 64) m->chunk_rays = (atoi(getenv("JUR_CHUNK_RAYS")) + 63) / 64 * 64;
   if (getenv("JUR_TRACE_MULT") && atoi(getenv("JUR_TRACE_MULT")) >= 1) m->trace_mult = atoi(getenv("JUR_TRACE_MULT"));
@@ -483,6 +494,13 @@ int jur_model_set_chunk_rays(jur_model_t *m, int rays) {
   return JUR_OK;
 }
 
+int jur_model_set_pencil(jur_model_t *m, long max_rays, int rays_per_group) {
+  if (max_rays < 0 || rays_per_group < 0 || rays_per_group > 64) { jur_set_error("set_pencil: max_rays >= 0, rays_per_group in 0..64"); return JUR_EINVAL; }
+  m->pencil_rays = max_rays;
+  m->pencil_rb = rays_per_group;
+  return JUR_OK;
+}
+
 int jur_model_enable_timing(jur_model_t *m, int on) {
   HIPCHK(hipSetDevice(m->device));
   if (on && !m->evpool) {
@@ -507,10 +525,20 @@ int jur_model_last_kernel_ms(jur_model_t *m, double out_ms[3], long out_launches
     float ms = 0;
     HIPCHK(hipEventSynchronize(m->evpool[2 * i + 1]));
     HIPCHK(hipEventElapsedTime(&ms, m->evpool[2 * i], m->evpool[2 * i + 1]));
-    out_ms[m->evkind[i]] += ms;
-    out_launches[m->evkind[i]]++;
+    if (m->evkind[i] < 3) { out_ms[m->evkind[i]] += ms; out_launches[m->evkind[i]]++; }
+    else { m->pencil_ms += ms; m->pencil_launches++; }
   }
   m->ntimed = 0;
+  return JUR_OK;
+}
+
+/* the fused kernel's share of the launches timed since the last call of this function (call
+ * jur_model_last_kernel_ms first: it collects the events) */
+int jur_model_last_pencil_ms(jur_model_t *m, double *out_ms, long *out_launches) {
+  *out_ms = m->pencil_ms;
+  *out_launches = m->pencil_launches;
+  m->pencil_ms = 0;
+  m->pencil_launches = 0;
   return JUR_OK;
 }
 
@@ -532,12 +560,25 @@ static int ensure_sort_buffers(jur_model_t *m, long nr) {
 int jur_model_reserve(jur_model_t *m, long nr) {
   if (!m || nr < 1 || nr > 0x7fffffffL) { jur_set_error("reserve: bad ray count"); return JUR_EINVAL; }
   HIPCHK(hipSetDevice(m->device));
+  if (pencil_rays_per_group(m, nr) > 0) return JUR_OK;      /* the fused kernel keeps its state in LDS */
   int rc = ensure_workspace(m, nr);
   if (rc == JUR_OK && m->sort_rays && nr > 64) rc = ensure_sort_buffers(m, nr);
   return rc;
 }
 
 /* ---- forward model ------------------------------------------------------------ */
+/* Rays per workgroup of the fused kernel for a call of nr rays, or 0 when the call goes to the batched kernels
+ * (too many rays, or more (channel, gas) chains per ray than the LDS rings hold).  One ray per workgroup while
+ * the chip has a CU slot for every ray (about 5 workgroups x 256 CUs), more rays per workgroup beyond that. */
+static int pencil_rays_per_group(jur_model_t const *m, long nr) {
+  if (m->pencil_rays <= 0 || nr > m->pencil_rays) return 0;
+  int rb = m->pencil_rb;
+  if (rb <= 0) rb = (nr <= 1280) ? 1 : (nr <= 2560) ? 2 : (nr <= 5120) ? 4 : 8;
+  if (rb > 64) rb = 64;
+  while (rb > 1 && jurk_pencil_lds_bytes(&m->view, rb) <= 0) rb /= 2;
+  return jurk_pencil_lds_bytes(&m->view, rb) > 0 ? rb : 0;
+}
+
 int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_rad, double *d_tau, double *d_tp,
                       int *d_np, int *d_status, void *stream) {
   if (!m || nr < 0) { jur_set_error("formod_device: bad arguments"); return JUR_EINVAL; }
@@ -545,11 +586,32 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
   if (nr > 0x7fffffffL) { jur_set_error("formod_device: at most 2^31-1 rays per call"); return JUR_EINVAL; }
   if (m->view.atm_np < 2) { jur_set_error("formod_device: no atmosphere set"); return JUR_EINVAL; }
   HIPCHK(hipSetDevice(m->device));
-  int rc = ensure_workspace(m, nr);
-  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   m->last_stream = stream;
   m->have_last_stream = 1;
+  int const rb = pencil_rays_per_group(m, nr);
+  if (rb > 0) {
+    /* a package-sized call: the whole path in one launch, a workgroup per rb rays, LOS state in LDS */
+    jur_chunk_t c;
+    memset(&c, 0, sizeof c);
+    c.n = (int)nr;
+    for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * nr;
+    for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * nr;
+    c.rad = d_rad;
+    c.tau = d_tau;
+    c.np_out = d_np;
+    c.status = d_status ? d_status : m->d_status;
+    if (m->host_call) HIPCHK(hipStreamWaitEvent(s, m->ev_mask, 0));
+    int const ti = (m->timing && m->ntimed < JUR_MAX_TIMED) ? m->ntimed++ : -1;
+    if (ti >= 0) { m->evkind[ti] = 3; HIPCHK(hipEventRecord(m->evpool[2 * ti], s)); }
+    int const e = jurk_launch_pencil(&m->view, &c, rb, s);
+    if (e) { jur_set_error("fused kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
+    if (ti >= 0) HIPCHK(hipEventRecord(m->evpool[2 * ti + 1], s));
+    if (m->host_call) HIPCHK(hipEventRecord(m->ev_trace, s));
+    return JUR_OK;
+  }
+  int rc = ensure_workspace(m, nr);
+  if (rc) return rc;
   long const R = m->use_rays;
   int const *order = NULL;
   if (m->sort_rays && nr > 64) {

@@ -65,6 +65,8 @@ def lib():
         L.jur_model_set_workspace_budget.argtypes = [C.c_void_p, C.c_long]
         L.jur_model_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_last_kernel_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
+        L.jur_model_last_pencil_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
+        L.jur_model_set_pencil.argtypes = [C.c_void_p, C.c_long, C.c_int]
         L.jur_state_size.restype = C.c_size_t
         L.jur_state_size.argtypes = [C.c_void_p, C.c_void_p]
         L.jur_measurement_size.restype = C.c_size_t
@@ -208,6 +210,10 @@ class Model:
     def reserve(self, nr):
         _chk(lib().jur_model_reserve(self.h, nr))
 
+    def set_pencil(self, max_rays, rays_per_group=0):
+        """Calls of up to max_rays rays run as one fused kernel (0: never)."""
+        _chk(lib().jur_model_set_pencil(self.h, max_rays, rays_per_group))
+
     def set_trace_multiple(self, mult):
         _chk(lib().jur_model_set_trace_multiple(self.h, mult))
 
@@ -288,8 +294,10 @@ class Model:
         ms = (C.c_double * 3)()
         n = (C.c_long * 3)()
         _chk(lib().jur_model_last_kernel_ms(self.h, ms, n))
+        pm, pn = C.c_double(0), C.c_long(0)
+        _chk(lib().jur_model_last_pencil_ms(self.h, C.byref(pm), C.byref(pn)))
         return dict(trace_ms=ms[0], ega_ms=ms[1], combine_ms=ms[2], trace_launches=n[0], ega_launches=n[1],
-                    combine_launches=n[2])
+                    combine_launches=n[2], pencil_ms=pm.value, pencil_launches=pn.value)
 
     def workspace_bytes(self):
         return lib().jur_model_workspace_bytes(self.h)

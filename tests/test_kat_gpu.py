@@ -145,7 +145,8 @@ def test_continua_on_the_window_edges(hip, oracle):
                 if not inside[k]:
                     assert np.all(got[k] == 0) and np.all(ref[k] == 0), (name, nu)
                     continue
-                assert np.any(ref[k] != 0), (name, nu)
+                strictly = [0 < nu < 4000, 0 < nu < 20000, 2120 < nu < 2605, 1360 < nu < 1805]
+                assert np.any(ref[k] != 0) or not strictly[k], (name, nu)    # (the N2 / O2 coefficients vanish at the edges)
                 # co2 is arithmetic only (same doubles); the others call exp / tanh / pow of the device library
                 tol = 0.0 if name == "co2" else 4e-15 if name in ("n2", "o2") else 2e-14
                 err = np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1e-300)
