@@ -162,7 +162,7 @@ int  jur_model_set_trace_multiple(jur_model_t *m, int mult);
  * transmittances); the rays-per-chunk shrink to fit.  Default 128 GiB of the 288 GB. */
 int  jur_model_set_workspace_budget(jur_model_t *m, long bytes);
 
-/* Calls of up to max_rays rays (default 4096; 0: never) run as ONE fused kernel -- ray tracing, emissivity growth
+/* Calls of up to max_rays rays (default 10000; 0: never) run as ONE fused kernel -- ray tracing, emissivity growth
  * and radiance update of a ray as producer/consumer wavefronts of one workgroup, the line of sight handed on through
  * LDS -- instead of the three batched kernels: the sizes the reference's callers use (packages of <= NR rays).
  * rays_per_group: rays per workgroup, 0 = chosen from the call size.  Configurations with more (channel, gas)

@@ -226,8 +226,9 @@ __device__ __attribute__((noinline)) ClipOut clip_exit(double px0, double px1, d
 //   L.begin_point(i)        called before point i is first written
 //   L.points_final(i)       called when points 0 .. i-1 will not change any more (point i still may: the exit
 //                           clipping rewrites the point before the exit, jr_common.h:645-646)
-//   L.ray_final(n, tsurf)   called when the ray has left the atmosphere with n points (not for a ray that runs into
-//                           the NLOS limit: see the returned np)
+//   L.ray_final(n, tsurf)   called as soon as the ray is known to have n points, all final: when it leaves the
+//                           atmosphere, or at once (n = 0) if it never enters it -- not for a ray that runs into the
+//                           NLOS limit: see the returned np
 // tr_sh: the per-lane tangent-point bookkeeping in LDS, column threadIdx.x.
 struct TraceResult { int np; double tsurf, tpz, tplon, tplat; };
 
@@ -270,6 +271,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
   }
 
   bool const outside = (obsz < zmin) || (vpz > zmax - 0.001);
+  if (outside) L.ray_final(0, -999.);     // (fused kernel: said before the other lanes start stepping)
   if (!outside) {
     double x[3], ex0[3], xobs[3], xvp[3];
     geo2cart(obsz, obslon, obslat, xobs);

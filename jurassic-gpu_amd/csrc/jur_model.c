@@ -195,7 +195,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   m->sort_rays = 1;
   m->ws_budget = 128L << 30;    /* of 288 GB HBM; C3 needs 96 KB per ray */
   m->trace_mult = 1;
-  m->pencil_rays = 4096;
+  m->pencil_rays = 10000;       /* measured crossover with the batched kernels (4 channels x 5 emitters) */
   m->pencil_rb = 0;
   if (getenv("JUR_PENCIL_RAYS")) m->pencil_rays = atol(getenv("JUR_PENCIL_RAYS"));
   if (getenv("JUR_PENCIL_RB")) m->pencil_rb = atoi(getenv("JUR_PENCIL_RB"));
@@ -568,12 +568,14 @@ int jur_model_reserve(jur_model_t *m, long nr) {
 
 /* ---- forward model ------------------------------------------------------------ */
 /* Rays per workgroup of the fused kernel for a call of nr rays, or 0 when the call goes to the batched kernels
- * (too many rays, or more (channel, gas) chains per ray than the LDS rings hold).  One ray per workgroup while
- * the chip has a CU slot for every ray (about 5 workgroups x 256 CUs), more rays per workgroup beyond that. */
+ * (too many rays, or more (channel, gas) chains per ray than the LDS rings hold). */
 static int pencil_rays_per_group(jur_model_t const *m, long nr) {
   if (m->pencil_rays <= 0 || nr > m->pencil_rays) return 0;
   int rb = m->pencil_rb;
-  if (rb <= 0) rb = (nr <= 1280) ? 1 : (nr <= 2560) ? 2 : (nr <= 5120) ? 4 : 8;
+  if (rb <= 0) {   /* measured (tools/bench_small.py): fastest with about 136 workgroups' worth of tracer wavefronts per call */
+    rb = 1;
+    while (rb < 16 && nr > 136L * rb) rb *= 2;
+  }
   if (rb > 64) rb = 64;
   while (rb > 1 && jurk_pencil_lds_bytes(&m->view, rb) <= 0) rb /= 2;
   return jurk_pencil_lds_bytes(&m->view, rb) > 0 ? rb : 0;

@@ -1,18 +1,32 @@
 #!/bin/bash
-# One gpurun call of a development round: GPU tests, instruction micro-benchmark, the bench line.
-# A step that had to be killed ends the call (no further GPU work on a device in an unknown state).
+# One gpurun call of a development round: GPU tests, the bench line, latency / concurrency tables, optional PMC
+# passes.  A step that had to be killed ends the call (no further GPU work on a device in an unknown state).
+#   usage: tools/gpu_round.sh <tag> [tests] [bench] [small] [lanes] [pmc] [micro]      (default: tests bench)
 mkdir -p gpurun_out
-TAG=${1:-r02}
+TAG=${1:-r02}; shift
+WHAT="${@:-tests bench}"
 step() { # name, seconds, command...
   name=$1; secs=$2; shift 2
   echo "== $name"
   timeout -k 10 "$secs" "$@" > "gpurun_out/${TAG}_$name.log" 2>&1
   rc=$?
-  tail -4 "gpurun_out/${TAG}_$name.log"
+  tail -${TAIL:-4} "gpurun_out/${TAG}_$name.log"
   if [ $rc -ge 124 ]; then echo "step $name killed (rc $rc): stopping"; exit $rc; fi
   return 0
 }
-step gpu_tests 900 python3 -m pytest tests -q -m gpu
-step microbench_build 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-result -o /tmp/microbench_valu tools/microbench_valu.hip
-step microbench 120 /tmp/microbench_valu
-step bench 600 python3 bench.py --steps 5
+for w in $WHAT; do
+  case $w in
+    tests) step gpu_tests 1100 python3 -m pytest tests -q -m gpu -p no:cacheprovider ;;
+    bench) TAIL=1 step bench 600 python3 bench.py --steps 5 ;;
+    nadir) TAIL=1 step bench_nadir 300 python3 bench.py --workload nadir_1e5 --steps 20 --no-cpu-baseline ;;
+    small) TAIL=1 step small 300 python3 tools/bench_small.py ;;
+    lanes) TAIL=5 step lanes 300 bash tools/run_lanes_bench.sh ;;
+    micro) step microbench_build 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-result -o /tmp/microbench_valu tools/microbench_valu.hip
+           TAIL=1 step microbench 120 /tmp/microbench_valu ;;
+    pmc)   PMC_SHORT=${PMC_SHORT-1} step pmc 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_pmc --rays 1000000 --steps 1 --warmup 0
+           step pmc_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc limb_1e6 1000000 gpurun_out/${TAG}_pmc_current.json ;;
+    stats) cd /tmp; export TMPDIR=/tmp
+           step kernel_stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --no-cpu-baseline --no-host-inclusive
+           cd $GRAFT_REPO_ROOT ;;
+  esac
+done

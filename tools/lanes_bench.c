@@ -43,6 +43,8 @@ int main(int argc, char **argv) {
     }
   }
   formod(ctl, atm, obs[0]);                                   /* loads the tables */
+#pragma omp parallel for num_threads(nthr) schedule(static, 1)
+  for (int t = 0; t < nthr; t++) formod(ctl, atm, obs[t]);    /* creates the lanes (streams, staging buffers): once per process */
   double const t0 = now();
 #pragma omp parallel for num_threads(nthr) schedule(static, 1)
   for (int t = 0; t < nthr; t++)

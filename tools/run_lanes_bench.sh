@@ -12,4 +12,5 @@ c = common.limb_case()
 c.write_files("$D", base="boxcar")
 PY
 cp "$ROOT/tests/golden/limb/atm.tab" .
-for t in 1 2 4 8 16; do JUR_LANES=$t "$ROOT/tools/lanes_bench" $t 8 | tail -1; done
+gcc -O2 -fopenmp -I"$ROOT/include" "$ROOT/tools/lanes_bench.c" -o "$D/lanes_bench" -L"$ROOT/jurassic-gpu_amd" -ljurassic_hip -Wl,-rpath,"$ROOT/jurassic-gpu_amd" -lm
+for t in 1 2 4 8 16; do JUR_LANES=$t $EXTRA_ENV "$D/lanes_bench" $t ${CALLS:-32} | tail -1; done
