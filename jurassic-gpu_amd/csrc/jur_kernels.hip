@@ -226,9 +226,9 @@ __device__ __attribute__((noinline)) ClipOut clip_exit(double px0, double px1, d
 //   L.begin_point(i)        called before point i is first written
 //   L.points_final(i)       called when points 0 .. i-1 will not change any more (point i still may: the exit
 //                           clipping rewrites the point before the exit, jr_common.h:645-646)
-//   L.ray_final(n, tsurf)   called as soon as the ray is known to have n points, all final: when it leaves the
-//                           atmosphere, or at once (n = 0) if it never enters it -- not for a ray that runs into the
-//                           NLOS limit: see the returned np
+//   L.never_enter(mask)     called once by all lanes together: the lanes whose rays never enter the atmosphere
+//   L.ray_final(n, tsurf)   called when the ray has left the atmosphere with n points, all final (not for a ray
+//                           that runs into the NLOS limit: see the returned np)
 // tr_sh: the per-lane tangent-point bookkeeping in LDS, column threadIdx.x.
 struct TraceResult { int np; double tsurf, tpz, tplon, tplat; };
 
@@ -271,7 +271,9 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
   }
 
   bool const outside = (obsz < zmin) || (vpz > zmax - 0.001);
-  if (outside) L.ray_final(0, -999.);     // (fused kernel: said before the other lanes start stepping)
+  // (fused kernel: which lanes' rays never enter the atmosphere is said by ONE lane, in its own program order
+  // before it starts stepping -- a branch of the lanes concerned could be scheduled behind the others' loop)
+  L.never_enter(__ballot(outside));
   if (!outside) {
     double x[3], ex0[3], xobs[3], xvp[3];
     geo2cart(obsz, obslon, obslat, xobs);
@@ -480,6 +482,7 @@ struct LosWorkspace {
   __device__ __forceinline__ void begin_point(int) const {}
   __device__ __forceinline__ void points_final(int) const {}
   __device__ __forceinline__ void ray_final(int, double) const {}
+  __device__ __forceinline__ void never_enter(unsigned long long) const {}
 };
 
 // 4 waves per SIMD (128 VGPRs, some scratch): measured 20 % faster than 2 waves without spills once a
@@ -1023,13 +1026,28 @@ struct LosRing {
     if (ip >= PEN_RING)
       while (min_cnt(ctl->cnt_comb, nc) + PEN_RING <= ip) __builtin_amdgcn_s_sleep(2);
   }
-  __device__ __forceinline__ void points_final(int np) const {
-    if (first_active_lane()) st_rel(&ctl->cnt_trace, np);
+  // Lanes whose rays left the atmosphere in this step have dropped out of the loop; their own announcement
+  // (ray_final) may be scheduled after the loop of the others, so a lane that is still stepping says it for them,
+  // in its own program order before the release of the next point: they stopped at point np, i.e. have np + 1 points.
+  __device__ __forceinline__ void points_final(int np) {
+    unsigned long long const cur = __ballot(1);
+    unsigned long long gone = running & ~cur;
+    running = cur;
+    if (first_active_lane()) {
+      for (; gone; gone &= gone - 1) st_rel(&npr[__ffsll((long long)gone) - 1], np + 2);
+      st_rel(&ctl->cnt_trace, np);
+    }
   }
   __device__ __forceinline__ void ray_final(int n, double ts) const {
     tsurf[r] = ts;
     st_rel(&npr[r], n + 1);
   }
+  __device__ __forceinline__ void never_enter(unsigned long long mask) {   // lane number == ray slot in wave 0
+    running = __ballot(1) & ~mask;
+    if (first_active_lane())
+      for (; mask; mask &= mask - 1) st_rel(&npr[__ffsll((long long)mask) - 1], 1);
+  }
+  unsigned long long running;
 };
 
 // wait until point ip is released (returns the released count c > ip) or the tracer is through (returns its final
@@ -1078,7 +1096,7 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
     // ---- tracer ----
     if (lane < nray) {
       long const ray = c.first + ray0 + lane;
-      LosRing L{ring, &ctl, npr, tsurf, nfield, RB, lane, NC};
+      LosRing L{ring, &ctl, npr, tsurf, nfield, RB, lane, NC, 0ull};
       TraceResult const t = trace_ray(v, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray], c.geom[4][ray],
                                       c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
       if (c.np_out) c.np_out[ray] = t.np;

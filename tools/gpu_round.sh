@@ -25,6 +25,20 @@ for w in $WHAT; do
            TAIL=1 step microbench 120 /tmp/microbench_valu ;;
     pmc)   PMC_SHORT=${PMC_SHORT-1} step pmc 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_pmc --rays 1000000 --steps 1 --warmup 0
            step pmc_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc limb_1e6 1000000 gpurun_out/${TAG}_pmc_current.json ;;
+    pencil) step pencil_tests 600 python3 -m pytest tests/test_pencil_gpu.py -q -p no:cacheprovider ;;
+    lanestrace) D=$(mktemp -d); ( cd $D && python3 - <<PY
+import sys
+sys.path[:0] = ["$GRAFT_REPO_ROOT", "$GRAFT_REPO_ROOT/jurassic-gpu_amd", "$GRAFT_REPO_ROOT/tests"]
+import common
+common.limb_case().write_files("$D", base="boxcar")
+PY
+           cp $GRAFT_REPO_ROOT/tests/golden/limb/atm.tab $D/
+           gcc -O2 -fopenmp -I$GRAFT_REPO_ROOT/include $GRAFT_REPO_ROOT/tools/lanes_bench.c -o $D/lanes_bench -L$GRAFT_REPO_ROOT/jurassic-gpu_amd -ljurassic_hip -Wl,-rpath,$GRAFT_REPO_ROOT/jurassic-gpu_amd -lm )
+           export TMPDIR=/tmp
+           ( cd $D && JUR_LANES=4 step lanes_trace 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_lanestrace -- $D/lanes_bench 4 8 )
+           for q in 1 2 8; do ( cd $D && echo "GPU_MAX_HW_QUEUES=$q" && GPU_MAX_HW_QUEUES=$q JUR_LANES=16 $D/lanes_bench 16 16 | tail -1 ); done > gpurun_out/${TAG}_lanes_hwq.log 2>&1
+           ( cd $D && echo "batched" && JUR_PENCIL_RAYS=0 JUR_LANES=16 $D/lanes_bench 16 16 | tail -1 ) >> gpurun_out/${TAG}_lanes_hwq.log 2>&1
+           cat gpurun_out/${TAG}_lanes_hwq.log ;;
     stats) cd /tmp; export TMPDIR=/tmp
            step kernel_stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --no-cpu-baseline --no-host-inclusive
            cd $GRAFT_REPO_ROOT ;;
