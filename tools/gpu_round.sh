@@ -3,14 +3,15 @@
 # passes.  A step that had to be killed ends the call (no further GPU work on a device in an unknown state).
 #   usage: tools/gpu_round.sh <tag> [tests] [bench] [small] [lanes] [pmc] [micro]      (default: tests bench)
 mkdir -p gpurun_out
+OUTDIR=$(pwd)/gpurun_out
 TAG=${1:-r02}; shift
 WHAT="${@:-tests bench}"
 step() { # name, seconds, command...
   name=$1; secs=$2; shift 2
   echo "== $name"
-  timeout -k 10 "$secs" "$@" > "gpurun_out/${TAG}_$name.log" 2>&1
+  timeout -k 10 "$secs" "$@" > "$OUTDIR/${TAG}_$name.log" 2>&1
   rc=$?
-  tail -${TAIL:-4} "gpurun_out/${TAG}_$name.log"
+  tail -${TAIL:-4} "$OUTDIR/${TAG}_$name.log"
   if [ $rc -ge 124 ]; then echo "step $name killed (rc $rc): stopping"; exit $rc; fi
   return 0
 }
@@ -36,8 +37,7 @@ PY
            gcc -O2 -fopenmp -I$GRAFT_REPO_ROOT/include $GRAFT_REPO_ROOT/tools/lanes_bench.c -o $D/lanes_bench -L$GRAFT_REPO_ROOT/jurassic-gpu_amd -ljurassic_hip -Wl,-rpath,$GRAFT_REPO_ROOT/jurassic-gpu_amd -lm )
            export TMPDIR=/tmp
            ( cd $D && JUR_LANES=4 step lanes_trace 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_lanestrace -- $D/lanes_bench 4 8 )
-           for q in 1 2 8; do ( cd $D && echo "GPU_MAX_HW_QUEUES=$q" && GPU_MAX_HW_QUEUES=$q JUR_LANES=16 $D/lanes_bench 16 16 | tail -1 ); done > gpurun_out/${TAG}_lanes_hwq.log 2>&1
-           ( cd $D && echo "batched" && JUR_PENCIL_RAYS=0 JUR_LANES=16 $D/lanes_bench 16 16 | tail -1 ) >> gpurun_out/${TAG}_lanes_hwq.log 2>&1
+           ( cd $D && echo "batched" && JUR_PENCIL_RAYS=0 JUR_LANES=16 $D/lanes_bench 16 16 | tail -1 ) > gpurun_out/${TAG}_lanes_hwq.log 2>&1
            cat gpurun_out/${TAG}_lanes_hwq.log ;;
     stats) cd /tmp; export TMPDIR=/tmp
            step kernel_stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --no-cpu-baseline --no-host-inclusive
