@@ -58,6 +58,8 @@ struct jur_model {
   double *d_io;                 /* geom[7][cap] tp[3][cap] rad/tau[cap][nd]      */
   int *d_io_np;
   long io_cap;
+  int *h_status;                /* pinned: the device status word comes back here (a pageable target would make the
+                                   copy a blocking one inside the runtime and serialise concurrent callers)      */
   double *h_io;                 /* pinned host image of d_io (+ np behind it) for callers with pageable arrays */
   long h_io_cap;
   double *h_pkg;                /* pinned scratch of the drop-in entry: rad/tau of one package, [2][NR][nd] */
@@ -111,7 +113,8 @@ static int check_ctl(ctl_t const *ctl) {
 }
 
 static int create_streams(jur_model_t *m) {
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipHostMalloc((void **)&m->h_status, 64, hipHostMallocDefault) != hipSuccess ||
+      hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_mask, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_trace, hipEventDisableTiming) != hipSuccess ||
@@ -251,6 +254,7 @@ void jur_model_destroy(jur_model_t *m) {
     if (ptrs[i]) (void)hipFree(ptrs[i]);
   if (m->h_io) (void)hipHostFree(m->h_io);
   if (m->h_pkg) (void)hipHostFree(m->h_pkg);
+  if (m->h_status) (void)hipHostFree(m->h_status);
   free(m->h_atm);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   if (m->stream2) (void)hipStreamDestroy(m->stream2);
@@ -778,8 +782,9 @@ int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double
     if ((rc = jur_formod_device(m, nr, d_geom, d_rad, d_tau, d_tp, m->d_io_np, m->d_status, s))) return rc;
     HIPCHK(hipMemcpyAsync(h_rad, d_rad, sizeof(double) * (2 * nrd + 3 * N), hipMemcpyDeviceToHost, s));
     if (np_out) HIPCHK(hipMemcpyAsync(h_np, m->d_io_np, sizeof(int) * N, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(m->h_status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    status = *m->h_status;
     memcpy(rad, h_rad, sizeof(double) * nrd);
     memcpy(tau, h_tau, sizeof(double) * nrd);
     for (int k = 0; k < 3; k++) memcpy(tp[k], h_tp + k * N, sizeof(double) * N);
@@ -822,12 +827,13 @@ int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double
     if (np_out) HIPCHK(hipMemcpyAsync(pin_np ? np_out : h_np, m->d_io_np, sizeof(int) * N, hipMemcpyDeviceToHost, s2));
     HIPCHK(hipMemcpyAsync(pin_rad ? rad : h_rad, d_rad, sizeof(double) * nrd, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(pin_tau ? tau : h_tau, d_tau, sizeof(double) * nrd, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(m->h_status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s2));             /* tangent points are here while the integration still runs */
     for (int k = 0; k < 3; k++)
       if (!pin_tp[k]) par_memcpy(tp[k], h_tp + k * N, sizeof(double) * N);
     if (np_out && !pin_np) par_memcpy(np_out, h_np, sizeof(int) * N);
     HIPCHK(hipStreamSynchronize(s));
+    status = *m->h_status;
     if (!pin_rad) par_memcpy(rad, h_rad, sizeof(double) * nrd);
     if (!pin_tau) par_memcpy(tau, h_tau, sizeof(double) * nrd);
   }
@@ -1111,7 +1117,7 @@ static jur_model_t *clone_lane(jur_model_t const *m) {
   c->los_bytes = 0; c->ws_rays = 0; c->ws_trace_rays = 0;
   c->d_order = NULL; c->d_sort_tmp = NULL; c->order_cap = 0; c->sort_tmp_bytes = 0;
   c->d_io = NULL; c->d_io_np = NULL; c->io_cap = 0;
-  c->h_io = NULL; c->h_io_cap = 0; c->h_pkg = NULL; c->h_atm = NULL; c->h_atm_n = 0; c->h_atm_cap = 0;
+  c->h_io = NULL; c->h_io_cap = 0; c->h_pkg = NULL; c->h_atm = NULL; c->h_atm_n = 0; c->h_atm_cap = 0; c->h_status = NULL;
   c->stream = NULL; c->stream2 = NULL; c->ev_mask = NULL; c->ev_trace = NULL; c->ev_side = NULL;
   c->host_call = 0; c->have_last_stream = 0; c->last_stream = NULL;
   c->timing = 0; c->evpool = NULL; c->evkind = NULL; c->ntimed = 0;
