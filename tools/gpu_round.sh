@@ -26,6 +26,7 @@ for w in $WHAT; do
            TAIL=1 step microbench 120 /tmp/microbench_valu ;;
     pmc)   PMC_SHORT=${PMC_SHORT-1} step pmc 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_pmc --rays 1000000 --steps 1 --warmup 0
            step pmc_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc limb_1e6 1000000 gpurun_out/${TAG}_pmc_current.json ;;
+    conc) TAIL=1 step concurrent 300 python3 tools/bench_concurrent.py ;;
     pencil) step pencil_tests 600 python3 -m pytest tests/test_pencil_gpu.py -q -p no:cacheprovider ;;
     lanestrace) D=$(mktemp -d); ( cd $D && python3 - <<PY
 import sys
