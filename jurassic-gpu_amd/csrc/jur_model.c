@@ -12,6 +12,7 @@
 #include <strings.h>
 #include <pthread.h>
 #include <unistd.h>
+#include <sched.h>
 #include <hip/hip_runtime_api.h>
 #include "jur_internal.h"
 
@@ -777,13 +778,25 @@ int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double
     int *const h_np = (int *)(h_tp + 3 * N);
     for (int k = 0; k < 7; k++) memcpy(h_geom + k * N, geom[k], sizeof(double) * N);
     memcpy(h_rad, rad, sizeof(double) * nrd);
-    HIPCHK(hipMemcpyAsync(d_geom, h_geom, sizeof(double) * (7 * N + nrd), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(m->d_status, 0, sizeof(int), s));
-    if ((rc = jur_formod_device(m, nr, d_geom, d_rad, d_tau, d_tp, m->d_io_np, m->d_status, s))) return rc;
-    HIPCHK(hipMemcpyAsync(h_rad, d_rad, sizeof(double) * (2 * nrd + 3 * N), hipMemcpyDeviceToHost, s));
-    if (np_out) HIPCHK(hipMemcpyAsync(h_np, m->d_io_np, sizeof(int) * N, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(m->h_status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    static int mode = -1;                        /* experiment switch: JUR_SMALL_MODE */
+    if (mode < 0) mode = getenv("JUR_SMALL_MODE") ? atoi(getenv("JUR_SMALL_MODE")) : 0;
+    if ((mode & 2) && pencil_rays_per_group(m, nr) > 0) {
+      /* zero-copy: the fused kernel reads the geometry from and writes the results to the pinned image itself */
+      *m->h_status = 0;
+      if ((rc = jur_formod_device(m, nr, h_geom, h_rad, h_tau, h_tp, np_out ? h_np : NULL, m->h_status, s))) return rc;
+    } else {
+      HIPCHK(hipMemcpyAsync(d_geom, h_geom, sizeof(double) * (7 * N + nrd), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemsetAsync(m->d_status, 0, sizeof(int), s));
+      if ((rc = jur_formod_device(m, nr, d_geom, d_rad, d_tau, d_tp, m->d_io_np, m->d_status, s))) return rc;
+      HIPCHK(hipMemcpyAsync(h_rad, d_rad, sizeof(double) * (2 * nrd + 3 * N), hipMemcpyDeviceToHost, s));
+      if (np_out) HIPCHK(hipMemcpyAsync(h_np, m->d_io_np, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(m->h_status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    if (mode & 1) {
+      hipError_t q;
+      while ((q = hipStreamQuery(s)) == hipErrorNotReady) sched_yield();
+      if (q != hipSuccess) { jur_set_error("stream failed: %s", hipGetErrorString(q)); return JUR_EHIP; }
+    } else HIPCHK(hipStreamSynchronize(s));
     status = *m->h_status;
     memcpy(rad, h_rad, sizeof(double) * nrd);
     memcpy(tau, h_tau, sizeof(double) * nrd);
