@@ -778,10 +778,11 @@ int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double
     int *const h_np = (int *)(h_tp + 3 * N);
     for (int k = 0; k < 7; k++) memcpy(h_geom + k * N, geom[k], sizeof(double) * N);
     memcpy(h_rad, rad, sizeof(double) * nrd);
-    static int mode = -1;                        /* experiment switch: JUR_SMALL_MODE */
-    if (mode < 0) mode = getenv("JUR_SMALL_MODE") ? atoi(getenv("JUR_SMALL_MODE")) : 0;
-    if ((mode & 2) && pencil_rays_per_group(m, nr) > 0) {
-      /* zero-copy: the fused kernel reads the geometry from and writes the results to the pinned image itself */
+    if (pencil_rays_per_group(m, nr) > 0 && !getenv("JUR_NO_ZERO_COPY")) {
+      /* The fused kernel reads the geometry from the pinned image and writes its results there itself (a few
+       * hundred KB over PCIe at the two ends of the kernel): ONE launch and one wait per call.  With copy
+       * commands around the kernel, concurrent callers (the lanes of the drop-in entry) were serialised by the
+       * runtime's copy path: 0.63 M rays/s with 16 threads against 1.9 M this way (tools/run_lanes_bench.sh). */
       *m->h_status = 0;
       if ((rc = jur_formod_device(m, nr, h_geom, h_rad, h_tau, h_tp, np_out ? h_np : NULL, m->h_status, s))) return rc;
     } else {
@@ -792,11 +793,7 @@ int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double
       if (np_out) HIPCHK(hipMemcpyAsync(h_np, m->d_io_np, sizeof(int) * N, hipMemcpyDeviceToHost, s));
       HIPCHK(hipMemcpyAsync(m->h_status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
     }
-    if (mode & 1) {
-      hipError_t q;
-      while ((q = hipStreamQuery(s)) == hipErrorNotReady) sched_yield();
-      if (q != hipSuccess) { jur_set_error("stream failed: %s", hipGetErrorString(q)); return JUR_EHIP; }
-    } else HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipStreamSynchronize(s));
     status = *m->h_status;
     memcpy(rad, h_rad, sizeof(double) * nrd);
     memcpy(tau, h_tau, sizeof(double) * nrd);
