@@ -73,12 +73,6 @@ struct jur_model {
   int host_call;                /* 1 while jur_formod_host drives jur_formod_device: record / wait for the events above */
   void *last_stream;            /* stream of the last jur_formod_device call (see jur_model_set_atm) */
   int have_last_stream;
-  /* large calls: sub-chunks of pipe_rays rays alternate between two internal streams, so that the ray tracing
-   * (latency-bound) and the radiance update (HBM-bound) of one sub-chunk run beside the emissivity-growth
-   * kernel (VALU-bound) of another */
-  long pipe_rays;               /* 0: one chunk after the other on the caller's stream              */
-  hipStream_t pstream[2];
-  hipEvent_t ev_fork, ev_stagger, ev_join[2];
   /* small calls: the fused kernel (jur_pencil_kernel) instead of sort + three batched kernels */
   long pencil_rays;             /* calls of up to this many rays take it (0: never)             */
   int pencil_rb;                /* rays per workgroup (0: chosen from the call size)            */
@@ -125,13 +119,7 @@ static int create_streams(jur_model_t *m) {
       hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_mask, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_trace, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess ||
-      hipStreamCreateWithFlags(&m->pstream[0], hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&m->pstream[1], hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&m->ev_stagger, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&m->ev_join[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&m->ev_join[1], hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess) {
     jur_set_error("cannot create the model's streams and events");
     return JUR_EHIP;
   }
@@ -211,8 +199,6 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   m->sort_rays = 1;
   m->ws_budget = 128L << 30;    /* of 288 GB HBM; C3 needs 96 KB per ray */
   m->trace_mult = 1;
-  m->pipe_rays = 0;
-  if (getenv("JUR_PIPE_RAYS")) m->pipe_rays = atol(getenv("JUR_PIPE_RAYS")) / 64 * 64;
   m->pencil_rays = 10000;       /* measured crossover with the batched kernels (4 channels x 5 emitters) */
   m->pencil_rb = 0;
   if (getenv("JUR_PENCIL_RAYS")) m->pencil_rays = atol(getenv("JUR_PENCIL_RAYS"));
@@ -276,12 +262,6 @@ void jur_model_destroy(jur_model_t *m) {
   if (m->ev_mask) (void)hipEventDestroy(m->ev_mask);
   if (m->ev_trace) (void)hipEventDestroy(m->ev_trace);
   if (m->ev_side) (void)hipEventDestroy(m->ev_side);
-  for (int j = 0; j < 2; j++) {
-    if (m->pstream[j]) (void)hipStreamDestroy(m->pstream[j]);
-    if (m->ev_join[j]) (void)hipEventDestroy(m->ev_join[j]);
-  }
-  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-  if (m->ev_stagger) (void)hipEventDestroy(m->ev_stagger);
   if (m->evpool) {
     for (int i = 0; i < 2 * JUR_MAX_TIMED; i++) (void)hipEventDestroy(m->evpool[i]);
     free(m->evpool);
@@ -653,70 +633,26 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     order = m->d_order;
   }
   long const Rt = m->use_trace_rays;
-#define TIMED(kind, launch, what, st)                                                          \
+#define TIMED(kind, launch, what)                                                              \
   do {                                                                                         \
     int const ti_ = (m->timing && m->ntimed < JUR_MAX_TIMED) ? m->ntimed++ : -1;               \
-    if (ti_ >= 0) { m->evkind[ti_] = (kind); HIPCHK(hipEventRecord(m->evpool[2 * ti_], st)); } \
+    if (ti_ >= 0) { m->evkind[ti_] = (kind); HIPCHK(hipEventRecord(m->evpool[2 * ti_], s)); } \
     int const e_ = (launch);                                                                   \
     if (e_) { jur_set_error(what " kernel launch failed: %s", hipGetErrorString((hipError_t)e_)); return JUR_EHIP; } \
-    if (ti_ >= 0) HIPCHK(hipEventRecord(m->evpool[2 * ti_ + 1], st));                          \
+    if (ti_ >= 0) HIPCHK(hipEventRecord(m->evpool[2 * ti_ + 1], s));                          \
   } while (0)
-  jur_chunk_t c;
-  c.stride = (int)Rt;
-  c.stride_eps = (int)R;
-  for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * nr;
-  for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * nr;
-  c.rad = d_rad;
-  c.tau = d_tau;
-  c.np_out = d_np;
-  c.status = d_status ? d_status : m->d_status;
-  long Rs = 0;
-  if (m->pipe_rays >= 64 && Rt == R && nr >= 2 * m->pipe_rays) {   /* equal shares of about pipe_rays rays, two of them in flight */
-    long nsub = (nr + m->pipe_rays / 2) / m->pipe_rays;
-    if (nsub < 2) nsub = 2;
-    for (;; nsub++) {
-      Rs = ((nr + nsub - 1) / nsub + 63) / 64 * 64;
-      if (2 * Rs <= R || Rs <= 64) break;
-    }
-    if (2 * Rs > R) Rs = 0;
-  }
-  if (Rs > 0) {
-    /* Pipelined sub-chunks.  The workspace of R ray slots is used as two slots of Rs rays; sub-chunk k runs
-     * trace -> ega -> combine on internal stream k % 2 in slot k % 2.  The second stream starts one ray-tracing
-     * launch late, so that from then on a trace or combine launch of one stream runs beside an ega launch of
-     * the other. */
-    long const nslot = 2;
-    HIPCHK(hipEventRecord(m->ev_fork, s));
-    for (int j = 0; j < 2; j++) HIPCHK(hipStreamWaitEvent(m->pstream[j], m->ev_fork, 0));
-    int masked[2] = {0, 0};
-    long k = 0;
-    for (long t0 = 0; t0 < nr; t0 += Rs, k++) {
-      hipStream_t const st = m->pstream[k & 1];
-      long const slot = k % nslot;
-      if (k == 1) HIPCHK(hipStreamWaitEvent(st, m->ev_stagger, 0));
-      c.n = (int)((nr - t0 < Rs) ? nr - t0 : Rs);
-      c.first = t0;
-      c.order = order ? order + t0 : NULL;
-      c.np = m->d_np + slot * Rs;
-      c.tsurf = m->d_tsurf + slot * Rs;
-      c.los = m->d_los + slot * Rs;
-      c.eps = m->d_eps + slot * Rs;
-      TIMED(0, jurk_launch_trace(&m->view, &c, st), "trace", st);
-      if (k == 0) HIPCHK(hipEventRecord(m->ev_stagger, st));
-      if (m->host_call && !masked[k & 1]) { HIPCHK(hipStreamWaitEvent(st, m->ev_mask, 0)); masked[k & 1] = 1; }
-      TIMED(1, jurk_launch_ega(&m->view, &c, st), "ega", st);
-      TIMED(2, jurk_launch_combine(&m->view, &c, st), "combine", st);
-    }
-    for (int j = 0; j < 2; j++) {
-      HIPCHK(hipEventRecord(m->ev_join[j], m->pstream[j]));
-      HIPCHK(hipStreamWaitEvent(s, m->ev_join[j], 0));
-    }
-    if (m->host_call) HIPCHK(hipEventRecord(m->ev_trace, s));
-    return JUR_OK;
-  }
   for (long t0 = 0; t0 < nr; t0 += Rt) {
+    jur_chunk_t c;
     long const nt = (nr - t0 < Rt) ? nr - t0 : Rt;
+    c.stride = (int)Rt;
+    c.stride_eps = (int)R;
+    for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * nr;
+    for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * nr;
+    c.rad = d_rad;
+    c.tau = d_tau;
+    c.np_out = d_np;
     c.eps = m->d_eps;
+    c.status = d_status ? d_status : m->d_status;
     /* trace the whole super-chunk */
     c.n = (int)nt;
     c.first = t0;
@@ -724,7 +660,7 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     c.np = m->d_np;
     c.tsurf = m->d_tsurf;
     c.los = m->d_los;
-    TIMED(0, jurk_launch_trace(&m->view, &c, s), "trace", s);
+    TIMED(0, jurk_launch_trace(&m->view, &c, s), "trace");
     if (m->host_call) {
       /* host entry: the input radiances, which only the epilogue reads (NaN mask), are uploaded beside the first
        * ray-tracing launch; tangent points and point counts are final after the last one and are copied out
@@ -740,8 +676,8 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
       c.np = m->d_np + s0;
       c.tsurf = m->d_tsurf + s0;
       c.los = m->d_los + s0;
-      TIMED(1, jurk_launch_ega(&m->view, &c, s), "ega", s);
-      TIMED(2, jurk_launch_combine(&m->view, &c, s), "combine", s);
+      TIMED(1, jurk_launch_ega(&m->view, &c, s), "ega");
+      TIMED(2, jurk_launch_combine(&m->view, &c, s), "combine");
     }
   }
 #undef TIMED
@@ -1193,7 +1129,6 @@ static jur_model_t *clone_lane(jur_model_t const *m) {
   c->d_io = NULL; c->d_io_np = NULL; c->io_cap = 0;
   c->h_io = NULL; c->h_io_cap = 0; c->h_pkg = NULL; c->h_atm = NULL; c->h_atm_n = 0; c->h_atm_cap = 0; c->h_status = NULL;
   c->stream = NULL; c->stream2 = NULL; c->ev_mask = NULL; c->ev_trace = NULL; c->ev_side = NULL;
-  c->pstream[0] = c->pstream[1] = NULL; c->ev_fork = c->ev_stagger = c->ev_join[0] = c->ev_join[1] = NULL;
   c->host_call = 0; c->have_last_stream = 0; c->last_stream = NULL;
   c->timing = 0; c->evpool = NULL; c->evkind = NULL; c->ntimed = 0;
   if (hipSetDevice(c->device) != hipSuccess || create_streams(c) != JUR_OK ||

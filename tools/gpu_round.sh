@@ -27,7 +27,6 @@ for w in $WHAT; do
     pmc)   PMC_SHORT=${PMC_SHORT-1} step pmc 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_pmc --rays 1000000 --steps 1 --warmup 0
            step pmc_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc limb_1e6 1000000 gpurun_out/${TAG}_pmc_current.json ;;
     lanesmode) for md in "JUR_NO_ZERO_COPY=1" "GPU_MAX_HW_QUEUES=8" "JUR_PENCIL_RAYS=0"; do echo "$md"; EXTRA_ENV="env $md" CALLS=16 bash tools/run_lanes_bench.sh 2>&1 | grep threads; done > $OUTDIR/${TAG}_lanesmode.log 2>&1; cat $OUTDIR/${TAG}_lanesmode.log ;;
-    pipe) TAIL=20 step pipe 900 bash tools/bench_pipe.sh ;;
     conc) TAIL=1 step concurrent 300 python3 tools/bench_concurrent.py ;;
     pencil) step pencil_tests 600 python3 -m pytest tests/test_pencil_gpu.py -q -p no:cacheprovider ;;
     lanestrace) D=$(mktemp -d); ( cd $D && python3 - <<PY
