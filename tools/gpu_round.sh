@@ -42,6 +42,8 @@ for w in $WHAT; do
            cd $GRAFT_REPO_ROOT
            PMC_SHORT=1 step nadir_pmc 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_nadir_pmc --workload nadir_1e5 --steps 1 --warmup 0
            step nadir_pmc_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_nadir_pmc nadir_1e5 100000 gpurun_out/${TAG}_nadir_pmc_summary.json ;;
+    cmpbuilds) TAIL=2 step compare_builds 600 python3 tools/compare_builds.py jurassic-gpu_amd/libjurassic_hip_prev.so jurassic-gpu_amd/libjurassic_hip.so 300000 ;;
+    kat) step kat 600 python3 -m pytest tests/test_kat_gpu.py -q -p no:cacheprovider ;;
     conc) TAIL=1 step concurrent 300 python3 tools/bench_concurrent.py ;;
     pencil) step pencil_tests 600 python3 -m pytest tests/test_pencil_gpu.py -q -p no:cacheprovider ;;
     lanestrace) D=$(mktemp -d); ( cd $D && python3 - <<PY
