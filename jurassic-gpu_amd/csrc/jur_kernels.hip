@@ -971,83 +971,6 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
   c.tau[oidx] = tau;
 }
 
-// jur_combine_group_kernel: the same update with CMB_G channels per lane.  The one-channel kernel above streams
-// the LOS rows of a ray block once per CHANNEL (PMC: its L2 hit rate is 12 %, 85 GB of HBM reads per 1e6 limb rays of
-// which 57 GB are the rows read four times, and it runs at 4.7 TB/s -- bandwidth-bound); here a lane loads p, T, ds
-// and the continuum columns of a point once and runs the channels of its group one after the other (unrolled:
-// independent exp / tanh chains side by side), so the rows cross the memory system once per group.  Per channel the
-// arithmetic and its order are those of the one-channel kernel: same doubles.
-#define CMB_G 4
-__global__ __launch_bounds__(256, 4) void jur_combine_group_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
-  int const nd = v.nd, ng = v.ng, ngrp = (nd + CMB_G - 1) / CMB_G;
-  int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
-  int const rb = (sq / ngrp) * 8 + xcd, grp = sq - (sq / ngrp) * ngrp;   // ray block, channel group: uniform
-  if (rb >= nrb) return;
-  int const d0 = grp * CMB_G, nch = min(CMB_G, nd - d0);
-  int const r = rb * blockDim.x + threadIdx.x;
-  double *const sr = reinterpret_cast<double *>(jur_lds);                // [CMB_G][TBLNS]
-  for (int i = threadIdx.x; i < nch * TBLNS; i += blockDim.x) sr[i] = v.sr[(size_t)d0 * TBLNS + i];
-  __syncthreads();
-  if (r >= c.n) return;
-  long const ray = c.order ? (long)c.order[r] : c.first + r;
-  size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
-  size_t const Re = (size_t)c.stride_eps, fe = (size_t)NLOS * Re;
-  double const *const los = c.los;
-  int const f_u = JUR_F_K + v.nw;
-  // what the group needs of a point, beyond p, T, ds (uniform)
-  bool any_co2 = false, any_h2o = false;
-  unsigned has_table[CMB_G];
-#pragma unroll
-  for (int dd = 0; dd < CMB_G; dd++) {
-    has_table[dd] = 0;
-    if (dd < nch) {
-      any_co2 |= (v.fourbit & 8) && v.chan[d0 + dd].co2_on;
-      any_h2o |= (v.fourbit & 4) && v.chan[d0 + dd].h2o_on;
-      for (int g = 0; g < ng && g < 32; g++) has_table[dd] |= (v.pair[g * nd + d0 + dd].a >= 2 ? 1u : 0u) << g;
-    }
-  }
-  double rad[CMB_G], tau[CMB_G];
-#pragma unroll
-  for (int dd = 0; dd < CMB_G; dd++) { rad[dd] = 0.0; tau[dd] = 1.0; }
-  int const np = c.np[r];
-  for (int ip = 0; ip < np; ++ip) {
-    size_t const o = (size_t)ip * R;
-    auto L = [&](int field) { return ldg<double>(los + (size_t)field * fs + o, r); };
-    double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
-    double const rt = 1. / t;
-    double const u_co2 = any_co2 ? L(f_u + v.ig_co2) : 0., q_h2o = any_h2o ? L(JUR_F_QH2O) : 0., u_h2o = any_h2o ? L(f_u + v.ig_h2o) : 0.;
-#pragma unroll
-    for (int dd = 0; dd < CMB_G; dd++) {
-      if (dd < nch) {
-        jur_chan_t const &ch = v.chan[d0 + dd];                          // uniform: scalar loads
-        double beta_ds = L(JUR_F_K + ch.window) * ds;
-        if ((v.fourbit & 8) && ch.co2_on) beta_ds += ctm_co2(ch, p, t, u_co2);
-        if ((v.fourbit & 4) && ch.h2o_on) beta_ds += ctm_h2o(ch, p, t, rt, q_h2o, u_h2o);
-        if ((v.fourbit & 2) && ch.n2_on) beta_ds += ctm_n2(ch, p, t, rt) * ds;
-        if ((v.fourbit & 1) && ch.o2_on) beta_ds += ctm_o2(ch, p, t, rt) * ds;
-        double const *const epsb = c.eps + (size_t)(d0 + dd) * ng * fe + (size_t)ip * Re;
-        double tau_gas = 1.0;
-        for (int g = 0; g < ng; g++)                                     // jr_common.h:272-278
-          if ((has_table[dd] >> g) & 1u) tau_gas *= ldg<double>(epsb + (size_t)g * fe, r);
-        new_obs_step(tau_gas, beta_ds, planck_src(sr + dd * TBLNS, t), rad[dd], tau[dd]);
-      }
-    }
-  }
-  double const tsurf = c.tsurf[r];
-#pragma unroll
-  for (int dd = 0; dd < CMB_G; dd++) {
-    if (dd < nch) {
-      size_t const oidx = (size_t)ray * nd + d0 + dd;
-      bool const masked = !isfinite(c.rad[oidx]);
-      double x = rad[dd];
-      ray_epilogue(sr + dd * TBLNS, v.chan[d0 + dd].nu, tsurf, v.write_bbt, x, tau[dd]);
-      if (masked) x = __builtin_nan("");
-      c.rad[oidx] = x;
-      c.tau[oidx] = tau[dd];
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // jur_pencil_kernel: the whole path of a ray pencil inside ONE workgroup -- for calls of the size the
 // reference's callers make (packages of <= NR = 1088 rays, formod.c:100, kernel() jurassic.c:844), which cannot
@@ -1462,15 +1385,6 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
   if (c->n <= 0) return 0;
   int const block = 256;
   int const nrb = (c->n + block - 1) / block;
-  static int grouped = -1;       // experiment switch
-  if (grouped < 0) grouped = getenv("JUR_COMBINE_GROUP") ? atoi(getenv("JUR_COMBINE_GROUP")) : 0;
-  if (grouped && v->nd > 1) {
-    int const ngrp = (v->nd + CMB_G - 1) / CMB_G;
-    unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * ngrp);
-    hipLaunchKernelGGL(jur_combine_group_kernel, dim3(grid), dim3(block), sizeof(double) * JUR_TBLNS * CMB_G, (hipStream_t)stream,
-                       *v, *c, nrb);
-    return (int)hipGetLastError();
-  }
   unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * v->nd);
   hipLaunchKernelGGL(jur_combine_kernel, dim3(grid), dim3(block), sizeof(double) * JUR_TBLNS, (hipStream_t)stream, *v, *c,
                      nrb);
