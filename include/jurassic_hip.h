@@ -143,6 +143,13 @@ int  jur_fov_read_shape(char const *filename, int *n, double *dz, double *w);
 int  jur_fov_apply(int nd, long nr, double const *time, double const *vpz, double *rad, double *tau, long ld,
                    int n, double const *dz, double const *w);
 
+/* The same convolution for results that stay in HBM (after jur_formod_device): d_time / d_vpz [nr] and
+ * d_rad / d_tau [nr][nd] in device memory of the model's GPU, convolved in place by a HIP kernel (one lane per
+ * ray and channel, the arithmetic of formod_fov in its order: bit-identical to jur_fov_apply); dz / w are host
+ * arrays.  Returns after the work on `stream` has finished; JUR_EINVAL if a ray is alone in its scan. */
+int  jur_fov_apply_device(jur_model_t *m, long nr, double const *d_time, double const *d_vpz, double *d_rad,
+                          double *d_tau, int n, double const *dz, double const *w, void *stream);
+
 /* Allocate the workspace for calls of up to nr rays now.  jur_formod_device allocates lazily on
  * first use; after jur_model_reserve (or one call of the same size) it only enqueues kernels on
  * the stream -- no allocation, no host synchronisation -- and can be captured into a HIP graph. */

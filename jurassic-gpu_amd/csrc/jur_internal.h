@@ -105,6 +105,10 @@ int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, double const *d
 long jurk_pencil_lds_bytes(jur_view_t const *v, int RB);
 int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int RB, void *stream);
 
+/* field-of-view convolution of device arrays: rad0/tau0 [nr][nd] -> rad/tau [nr][ld]; status bit 1: a ray alone in its scan */
+int jurk_launch_fov(long nr, int nd, double const *time, double const *vpz, double const *rad0, double const *tau0, double *rad,
+                    double *tau, long ld, int n, double const *dz, double const *w, int *status, void *stream);
+
 /* known-answer hooks (tests): device functions on arrays, see jurassic_hip.h */
 int jurk_kat_ega(jur_view_t const *v, int g, int d, long n, double const *tau, double const *t, double const *u, double const *p,
                  int mode, int chain, double *out, void *stream);

@@ -1000,6 +1000,14 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
 #define PEN_MAXE 8        // at most this many ega / combine waves per workgroup
 #define PEN_MAXC 4
 
+// doubles of dynamic LDS in front of the optional profile slab (rings, chain and radiance state, per-ray results,
+// the 32-bit state rounded up to whole doubles)
+__host__ __device__ inline long pen_lds_doubles(int nd, int ng, int nw, int RB) {
+  long const npair = (long)nd * ng, nfield = JUR_F_K + nw + ng, nchain = RB * npair, nitem = (long)RB * nd;
+  long const n1 = nchain > 0 ? nchain : 1;
+  return (long)PEN_RING * nfield * RB + (long)PEN_RINGE * (npair > 0 ? npair : 1) * RB + n1 + 2 * nitem + RB + (3 * n1 + RB + 1) / 2 + 2;
+}
+
 struct PenCtl {            // LDS, one per workgroup
   int cnt_trace, done;
   int cnt_ega[PEN_MAXE];
@@ -1065,10 +1073,25 @@ __device__ __forceinline__ int wait_point(PenCtl *ctl, int ip) {
   }
 }
 
+// first point of the profile slice with this time stamp (the first search of locate_atm, jr_common.h:130-140)
+__device__ __forceinline__ int slice_start(double const *__restrict__ atm_time, int atm_np, double time) {
+  int lo = 0, hi = atm_np - 1;
+  while (hi > lo + 1) {
+    int const i = (lo + hi) / 2;
+    if (atm_time[i] < time) lo = i; else hi = i;
+  }
+  return (0 == lo) ? lo : hi;
+}
+
+// atm_cap > 0: the dynamic LDS block ends in room for (7 + ng + nw) rows of atm_cap doubles -- the profile slice of
+// the workgroup's rays (time, z, lon, lat, p, T, q[], k[], ln-p slope), copied there when all its rays use the same
+// slice.  The tracer's per-step profile gathers (a chain of dependent loads at L2 latency when one wave per SIMD
+// has nothing to hide them behind) then stay inside the CU.  Same numbers from another place: same results.
 template <bool WARM>
-__global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chunk_t c, int RB, int NE, int NC) {
+__global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chunk_t c, int RB, int NE, int NC, int atm_cap) {
   __shared__ double tr_sh[15][64];
   __shared__ PenCtl ctl;
+  __shared__ int sl_lo, sl_hi;
   int const nd = v.nd, ng = v.ng, npair = nd * ng, nfield = JUR_F_K + v.nw + ng;
   int const nchain = RB * npair, nitem = RB * nd;
   // dynamic LDS: rings, chain state, per-(ray, channel) radiance state, per-ray results of the tracer
@@ -1093,15 +1116,59 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
     ctl.cnt_trace = 0; ctl.done = 0;
     for (int i = 0; i < PEN_MAXE; i++) ctl.cnt_ega[i] = 0;
     for (int i = 0; i < PEN_MAXC; i++) ctl.cnt_comb[i] = 0;
+    sl_lo = 0x7fffffff; sl_hi = -1;
   }
   __syncthreads();
+  jur_view_t vt = v;                            // the tracer's view of the atmosphere
+  if (atm_cap > 0) {
+    if (tid < nray) {                           // do all rays of the workgroup use one slice?
+      double const time = c.geom[0][c.first + ray0 + tid];
+      int const a0 = slice_start(v.atm_time, v.atm_np, time);
+      atomicMin(&sl_lo, a0);
+      atomicMax(&sl_hi, (v.atm_time[a0] == time) ? a0 : 0x7ffffffe);   // a time stamp without a profile: no copy
+    }
+    __syncthreads();
+    int const a0 = sl_lo;
+    if (a0 == sl_hi) {
+      // its extent: the points that share the first one's time stamp (time stamps are sorted when atm_sorted;
+      // otherwise no copy is made)
+      int n = 0;
+      if (v.atm_sorted) {
+        double const t0 = v.atm_time[a0];
+        int lo = a0, hi = v.atm_np;              // first index in (a0, atm_np] whose time differs
+        while (hi > lo + 1) {
+          int const i = (lo + hi) / 2;
+          if (v.atm_time[i] == t0) lo = i; else hi = i;
+        }
+        n = hi - a0;
+      }
+      if (n >= 2 && n <= atm_cap) {
+        int const nrow = 7 + ng + v.nw;
+        double *const slab = reinterpret_cast<double *>(jur_lds) + pen_lds_doubles(nd, ng, v.nw, RB);
+        double const *const rows[7] = {v.atm_time, v.atm_z, v.atm_lon, v.atm_lat, v.atm_p, v.atm_t, v.atm_pslope};
+        for (int i = tid; i < nrow * n; i += blockDim.x) {
+          int const row = i / n, k = i - row * n;
+          double x;
+          if (row < 7) x = rows[row][a0 + k];
+          else if (row < 7 + ng) x = v.atm_q[(size_t)(row - 7) * v.atm_np + a0 + k];
+          else x = v.atm_k[(size_t)(row - 7 - ng) * v.atm_np + a0 + k];
+          slab[(size_t)row * n + k] = x;
+        }
+        vt.atm_np = n;
+        vt.atm_time = slab; vt.atm_z = slab + n; vt.atm_lon = slab + 2 * n; vt.atm_lat = slab + 3 * n;
+        vt.atm_p = slab + 4 * n; vt.atm_t = slab + 5 * n; vt.atm_pslope = slab + 6 * n;
+        vt.atm_q = slab + 7 * (size_t)n; vt.atm_k = slab + (7 + (size_t)ng) * n;
+        __syncthreads();                          // (uniform branch: every thread of the workgroup is here)
+      }
+    }
+  }
 
   if (wave == 0) {
     // ---- tracer ----
     if (lane < nray) {
       long const ray = c.first + ray0 + lane;
       LosRing L{ring, &ctl, npr, tsurf, nfield, RB, lane, NC, 0ull};
-      TraceResult const t = trace_ray(v, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray], c.geom[4][ray],
+      TraceResult const t = trace_ray(vt, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray], c.geom[4][ray],
                                       c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
       if (c.np_out) c.np_out[ray] = t.np;
       c.tp[0][ray] = t.tpz;
@@ -1278,6 +1345,42 @@ __global__ __launch_bounds__(256) void jur_raykey_kernel(long nr, double const *
   }
   key[r] = (slice << 32) | ord;
   id[r] = (int)r;
+}
+
+// ---------------------------------------------------------------------------------------
+// field-of-view convolution on device arrays (formod_fov, jurassic.c:214-258): for callers that keep the
+// radiances in HBM.  One lane per (ray, channel); the neighbours' profile is gathered per lane, the weights are
+// walked in the reference's order with its arithmetic (jur_fov.c is the host twin, bit-identical).
+// rad0 / tau0: the forward model's results [nr][nd]; rad / tau: the convolved ones [nr][ld].
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jur_fov_kernel(long nr, int nd, double const *__restrict__ time, double const *__restrict__ vpz,
+                                                      double const *__restrict__ rad0, double const *__restrict__ tau0,
+                                                      double *__restrict__ rad, double *__restrict__ tau, long ld, int n,
+                                                      double const *__restrict__ dz, double const *__restrict__ w,
+                                                      int *__restrict__ status) {
+  long const i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nr * nd) return;
+  long const ir = i / nd;
+  int const id = (int)(i - ir * nd);
+  double z[2 * JUR_NFOV + 1];
+  long src[2 * JUR_NFOV + 1];
+  int nz = 0;
+  long const lo = ir - JUR_NFOV > 0 ? ir - JUR_NFOV : 0, hi = ir + 1 + JUR_NFOV < nr ? ir + 1 + JUR_NFOV : nr;
+  for (long ir2 = lo; ir2 < hi; ir2++)
+    if (time[ir2] == time[ir]) { z[nz] = vpz[ir2]; src[nz] = ir2; nz++; }
+  if (nz < 2) { atomicOr(status, 2); return; }          // "Cannot apply FOV convolution!" upstream
+  double r = 0, t = 0, wsum = 0;
+  for (int k = 0; k < n; k++) {
+    double const zfov = vpz[ir] + dz[k];
+    int const idx = locate_axis(z, nz, zfov);
+    double const r0 = rad0[src[idx] * nd + id], r1 = rad0[src[idx + 1] * nd + id];
+    double const t0 = tau0[src[idx] * nd + id], t1 = tau0[src[idx + 1] * nd + id];
+    r += w[k] * (r0 + (zfov - z[idx]) * (r1 - r0) / (z[idx + 1] - z[idx]));
+    t += w[k] * (t0 + (zfov - z[idx]) * (t1 - t0) / (z[idx + 1] - z[idx]));
+    wsum += w[k];
+  }
+  rad[ir * ld + id] = r / wsum;
+  tau[ir * ld + id] = t / wsum;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1471,11 +1574,15 @@ extern "C" int jurk_kat_update(jur_view_t const *v, int d, long n, int what, dou
 // ---- fused kernel for small calls ----
 // LDS bytes jur_pencil_kernel needs for RB rays per workgroup (0: the configuration does not fit)
 extern "C" long jurk_pencil_lds_bytes(jur_view_t const *v, int RB) {
-  long const npair = (long)v->nd * v->ng, nfield = JUR_F_K + v->nw + v->ng, nchain = RB * npair, nitem = (long)RB * v->nd;
-  long const n1 = nchain > 0 ? nchain : 1;
-  long const bytes = 8 * ((long)PEN_RING * nfield * RB + (long)PEN_RINGE * (npair > 0 ? npair : 1) * RB + n1 + 2 * nitem + RB) +
-                     4 * (3 * n1 + RB) + 64;
+  long const bytes = 8 * pen_lds_doubles(v->nd, v->ng, v->nw, RB);
   return bytes <= 96 * 1024 ? bytes : 0;
+}
+
+// room for the profile slab: the longest slice of the atmosphere, if that stays inside 32 KB
+static int pencil_atm_cap(jur_view_t const *v) {
+  long const nrow = 7 + v->ng + v->nw;
+  if (!v->atm_sorted || v->atm_maxslice < 2 || getenv("JUR_PENCIL_NO_ATM_LDS")) return 0;
+  return (nrow * v->atm_maxslice * 8 <= 32 * 1024) ? v->atm_maxslice : 0;
 }
 
 extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int RB, void *stream) {
@@ -1488,13 +1595,24 @@ extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int
   NC = NC < 1 ? 1 : (NC > PEN_MAXC ? PEN_MAXC : NC);
   dim3 const grid((unsigned)((c->n + RB - 1) / RB)), block((unsigned)(64 * (1 + NE + NC)));
   hipStream_t s = (hipStream_t)stream;
+  int const atm_cap = pencil_atm_cap(v);
+  long const lds_all = lds + 8L * (7 + v->ng + v->nw) * atm_cap;
   static bool raised = false;      // dynamic LDS beyond 64 KB needs the attribute once per kernel
   if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     raised = true;
   }
-  if (v->sorted_tables) hipLaunchKernelGGL(jur_pencil_kernel<true>, grid, block, (size_t)lds, s, *v, *c, RB, NE, NC);
-  else hipLaunchKernelGGL(jur_pencil_kernel<false>, grid, block, (size_t)lds, s, *v, *c, RB, NE, NC);
+  if (v->sorted_tables) hipLaunchKernelGGL(jur_pencil_kernel<true>, grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
+  else hipLaunchKernelGGL(jur_pencil_kernel<false>, grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_launch_fov(long nr, int nd, double const *time, double const *vpz, double const *rad0, double const *tau0,
+                               double *rad, double *tau, long ld, int n, double const *dz, double const *w, int *status, void *stream) {
+  if (nr <= 0) return 0;
+  long const total = nr * nd;
+  hipLaunchKernelGGL(jur_fov_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nr, nd, time, vpz, rad0,
+                     tau0, rad, tau, ld, n, dz, w, status);
   return (int)hipGetLastError();
 }

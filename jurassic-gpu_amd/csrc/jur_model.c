@@ -918,6 +918,37 @@ done:
   return rc;
 }
 
+/* ---- field-of-view convolution of results that stay on the device ------------------- */
+int jur_fov_apply_device(jur_model_t *m, long nr, double const *d_time, double const *d_vpz, double *d_rad, double *d_tau,
+                         int n, double const *dz, double const *w, void *stream) {
+  if (!m || nr < 1 || n < 1 || n > JUR_NSHAPE || !d_time || !d_vpz || !d_rad || !d_tau || !dz || !w) {
+    jur_set_error("jur_fov_apply_device: bad arguments");
+    return JUR_EINVAL;
+  }
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = (hipStream_t)stream;
+  int const nd = m->view.nd;
+  size_t const vals = (size_t)nr * nd;
+  double *tmp = NULL;                          /* rad0 | tau0 | dz | w : every ray reads the UNconvolved neighbours */
+  HIPCHK(hipMalloc((void **)&tmp, sizeof(double) * (2 * vals + 2 * (size_t)n)));
+  int rc = JUR_OK, status = 0;
+  hipError_t e = hipMemcpyAsync(tmp, d_rad, sizeof(double) * vals, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(tmp + vals, d_tau, sizeof(double) * vals, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(tmp + 2 * vals, dz, sizeof(double) * n, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(tmp + 2 * vals + n, w, sizeof(double) * n, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(m->d_status, 0, sizeof(int), s);
+  if (e == hipSuccess)
+    e = (hipError_t)jurk_launch_fov(nr, nd, d_time, d_vpz, tmp, tmp + vals, d_rad, d_tau, nd, n, tmp + 2 * vals, tmp + 2 * vals + n,
+                                    m->d_status, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->h_status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { jur_set_error("jur_fov_apply_device: %s", hipGetErrorString(e)); rc = JUR_EHIP; }
+  else status = *m->h_status;
+  (void)hipFree(tmp);
+  if (!rc && (status & 2)) { jur_set_error("Cannot apply FOV convolution!"); rc = JUR_EINVAL; }
+  return rc;
+}
+
 /* ---- known-answer hooks ----------------------------------------------------------- */
 /* nin input arrays and nout in/out arrays of n doubles each go to the device as one slab [nin + nout][n] */
 static int kat_slab(jur_model_t *m, long n, int nin, double const *const in[], int nout, double *const out[], double **d) {

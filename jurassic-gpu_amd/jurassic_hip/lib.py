@@ -51,6 +51,7 @@ def lib():
         L.jur_model_set_atm.argtypes = [C.c_void_p, C.c_void_p]
         L.jur_formod_host.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
         L.jur_curtis_godson_host.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), dp, dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
+        L.jur_fov_apply_device.argtypes = [C.c_void_p, C.c_long] + [C.c_void_p] * 4 + [C.c_int, dp, dp, C.c_void_p]
         L.jur_host_alloc.restype = C.c_void_p
         L.jur_host_alloc.argtypes = [C.c_size_t]
         L.jur_host_free.argtypes = [C.c_void_p]
@@ -256,6 +257,11 @@ class Model:
     def formod_device(self, nr, d_geom, d_rad, d_tau, d_tp, d_np=0, d_status=0, stream=0):
         """All arguments are raw device addresses (ints), e.g. torch_tensor.data_ptr()."""
         _chk(lib().jur_formod_device(self.h, nr, d_geom, d_rad, d_tau, d_tp, d_np, d_status, stream))
+
+    def fov_apply_device(self, nr, d_time, d_vpz, d_rad, d_tau, dz, w, stream=0):
+        """Field-of-view convolution of device arrays in place (raw device addresses as for formod_device)."""
+        dz, w = (np.ascontiguousarray(a, dtype=np.float64) for a in (dz, w))
+        _chk(lib().jur_fov_apply_device(self.h, nr, d_time, d_vpz, d_rad, d_tau, len(dz), _p(dz), _p(w), stream))
 
     def kernel(self, atm, obs):
         """Forward-difference Jacobian (m, n); obs receives the unperturbed forward model."""

@@ -861,3 +861,46 @@ def test_nlos_overflow_is_reported(hip):
     with pytest.raises(hip.JurassicError, match="Too many LOS points"):
         model.formod_host(case.geom)
     model.close()
+
+
+def test_fov_convolution_on_device_arrays(hip, oracle):
+    """formod_fov (jurassic.c:214-258) as a HIP kernel on results that stay in HBM: three limb scans through
+    jur_formod_device, convolved in place by jur_fov_apply_device -- bit-identical to the oracle's restatement
+    of formod_fov and to the library's host twin; a ray alone in its scan is refused as upstream aborts."""
+    import torch
+    scans, per = 3, 40
+    geom = np.vstack([synth.limb_geometry(per, scan=True, zmin=5.0, zmax=44.0) for _ in range(scans)])
+    geom[:, 0] = np.repeat(np.arange(scans, dtype=float), per)          # one time stamp per scan
+    case = common.limb_case(geom=geom)
+    base = textio.read_atm(os.path.join(common.GOLD, "limb", "atm.tab"), case.ctl)
+    case.atm = synth.stack_profiles(base, case.ctl, scans, seed=3)       # a profile per time stamp
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    dev = torch.device("cuda", 0)
+    nr, nd = len(geom), case.ctl.nd
+    d_geom = torch.from_numpy(np.ascontiguousarray(geom.T)).to(dev)
+    d_rad = torch.zeros((nr, nd), dtype=torch.float64, device=dev)
+    d_tau = torch.zeros((nr, nd), dtype=torch.float64, device=dev)
+    d_tp = torch.zeros((3, nr), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    model.formod_device(nr, d_geom.data_ptr(), d_rad.data_ptr(), d_tau.data_ptr(), d_tp.data_ptr(), 0, 0, stream)
+    torch.cuda.synchronize()
+    rad0, tau0 = d_rad.cpu().numpy().copy(), d_tau.cpu().numpy().copy()
+    dz = np.linspace(-1.5, 1.5, 21)
+    w = np.exp(-0.5 * (dz / 0.6) ** 2)
+    model.fov_apply_device(nr, d_geom[0].data_ptr(), d_geom[4].data_ptr(), d_rad.data_ptr(), d_tau.data_ptr(), dz, w, stream)
+    got_r, got_t = d_rad.cpu().numpy(), d_tau.cpu().numpy()
+    assert not np.array_equal(got_r, rad0)
+    host_r, host_t = rad0.copy(), tau0.copy()                            # the library's host twin
+    hip.fov_apply(geom[:, 0], geom[:, 4], host_r, host_t, dz, w)
+    assert np.array_equal(got_r.view(np.uint64), host_r.view(np.uint64)) and np.array_equal(got_t.view(np.uint64), host_t.view(np.uint64))
+    obs = _obs_from_geom(geom, nd)                                        # the oracle's restatement of formod_fov
+    np.ctypeslib.as_array(obs.rad)[:nr, :nd] = rad0
+    np.ctypeslib.as_array(obs.tau)[:nr, :nd] = tau0
+    assert oracle.formod_fov(case.ctl, obs, dz, w) == 0
+    assert np.array_equal(np.ctypeslib.as_array(obs.rad)[:nr, :nd].view(np.uint64), got_r.view(np.uint64))
+    assert np.array_equal(np.ctypeslib.as_array(obs.tau)[:nr, :nd].view(np.uint64), got_t.view(np.uint64))
+    lone = torch.tensor([0.0, 1.0, 1.0], dtype=torch.float64, device=dev)            # first ray alone in its scan
+    with pytest.raises(hip.JurassicError, match="Cannot apply FOV"):
+        model.fov_apply_device(3, lone.data_ptr(), d_geom[4].data_ptr(), d_rad.data_ptr(), d_tau.data_ptr(), dz, w, stream)
+    model.close()
