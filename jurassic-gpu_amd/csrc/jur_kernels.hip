@@ -22,6 +22,12 @@
 //   jur_raykey_kernel     geometric tangent altitude per ray; rays are then processed in
 //                         that order (hipCUB radix sort) so that the lanes of a wavefront
 //                         walk similar paths.
+//   jur_pencil_kernel     package-sized calls: the whole path of a few rays in ONE workgroup -- a tracer wavefront,
+//                         emissivity-growth wavefronts (lane per (ray, channel, gas) chain) and radiance-update
+//                         wavefronts hand the line of sight on through rings in LDS while it is being traced; the
+//                         same device functions as the three batched kernels, bit-identical results.
+//   jur_fov_kernel        field-of-view convolution of device arrays (formod_fov, jurassic.c:214-258).
+//   jur_kat_*_kernel      known-answer hooks for tests: the device functions on arrays of inputs.
 //
 // All arithmetic is IEEE fp64 with the reference's operand order; tables are fp32 in memory.
 // Compiled with -ffp-contract=off so that no fused multiply-adds are formed that the
