@@ -45,6 +45,7 @@ for w in $WHAT; do
     cmpbuilds) TAIL=2 step compare_builds 600 python3 tools/compare_builds.py jurassic-gpu_amd/libjurassic_hip_prev.so jurassic-gpu_amd/libjurassic_hip.so 300000 ;;
     kat) step kat 600 python3 -m pytest tests/test_kat_gpu.py -q -p no:cacheprovider ;;
     ab) TAIL=20 step ab 900 bash tools/ab_env.sh $AB ;;
+    fuzz) TAIL=3 step fuzz 1100 python3 tools/fuzz_parity.py ${FUZZ:-3000 400} ;;
     conc) TAIL=1 step concurrent 300 python3 tools/bench_concurrent.py ;;
     pencil) step pencil_tests 600 python3 -m pytest tests/test_pencil_gpu.py -q -p no:cacheprovider ;;
     lanestrace) D=$(mktemp -d); ( cd $D && python3 - <<PY
