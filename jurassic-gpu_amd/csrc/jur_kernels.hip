@@ -224,6 +224,15 @@ __device__ __attribute__((noinline)) ClipOut clip_exit(double px0, double px1, d
 #define TR_LZ2 tr_sh[10][threadIdx.x]
 #define TR_LX2(i) tr_sh[11 + (i)][threadIdx.x]
 #define TR_LDS2 tr_sh[14][threadIdx.x]
+// value of lane K of the caller's quad (lanes 4q .. 4q+3), for all four lanes: two DPP moves
+template <int K>
+__device__ __forceinline__ double quad_bcast(double x) {
+  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);               // quad_perm:[K,K,K,K]
+  int const lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xf, 0xf, false);
+  int const hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 // One line of sight (traceray, jr_common.h:585-711, with tangent_point :502-539, trapezoid_rule_pos :437-443 and
 // column_density :446-453 folded in), one lane per ray.  L says where the LOS fields of a point live -- the HBM
 // workspace of the batched kernels, or a ring in LDS in the fused kernel -- through
@@ -236,9 +245,15 @@ __device__ __attribute__((noinline)) ClipOut clip_exit(double px0, double px1, d
 //   L.ray_final(n, tsurf)   called when the ray has left the atmosphere with n points, all final (not for a ray
 //                           that runs into the NLOS limit: see the returned np)
 // tr_sh: the per-lane tangent-point bookkeeping in LDS, column threadIdx.x.
+// QUAD: the ray is traced by the four lanes of a quad together (fused kernel, where the tracer wavefront has lanes
+// to spare and the call's latency is the tracer's dependent instruction chain).  All four run the step
+// redundantly -- same inputs, same doubles -- except for the refractivity gradient (jr_common.h:665-681), 58 % of
+// the step's instructions: lane 0 takes the centre probe, lanes 1..3 one displaced probe each, and the four
+// refractivities are exchanged with DPP moves.  Each probe is evaluated exactly as the sequential loop evaluates
+// it (including the coordinates the loop has displaced and restored before it), so the results are the same doubles.
 struct TraceResult { int np; double tsurf, tpz, tplon, tplat; };
 
-template <class Los>
+template <class Los, bool QUAD = false>
 __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double const time, double const obsz, double const obslon,
                                                  double const obslat, double const vpz, double const vplon, double const vplat,
                                                  Los &L, double (&tr_sh)[15][64], int *status) {
@@ -404,6 +419,22 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
         n += refractivity(p, t);
         double xh[3], zz, llon, llat, pp, tt;
         for (int i = 0; i < 3; i++) xh[i] = x[i] + 0.5 * ds * ex0[i];
+        if constexpr (QUAD) {
+          // one probe per lane of the quad.  The sequential loop displaces a coordinate by h, probes, and takes h
+          // off again before it goes on: probe i sees (x_k + h) - h in the coordinates k < i
+          double const h = 0.02;
+          int const j = threadIdx.x & 3;
+          double const r0 = (xh[0] + h) - h, r1 = (xh[1] + h) - h;
+          double const xq[3] = {(j == 1) ? xh[0] + h : (j >= 2) ? r0 : xh[0], (j == 2) ? xh[1] + h : (j == 3) ? r1 : xh[1],
+                                (j == 3) ? xh[2] + h : xh[2]};
+          cart2geo(xq, zz, llon, llat);
+          double rdzb = 0;
+          intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb);   // (lip_rcp == lip: same doubles as the plain search)
+          double const nj = refractivity(pp, tt), n2 = quad_bcast<0>(nj);
+          ngr[0] = div_rcp(quad_bcast<1>(nj) - n2, h, 1. / h);
+          ngr[1] = div_rcp(quad_bcast<2>(nj) - n2, h, 1. / h);
+          ngr[2] = div_rcp(quad_bcast<3>(nj) - n2, h, 1. / h);
+        } else {
         cart2geo(xh, zz, llon, llat);
         double rdzb = 0;
         int const ib = intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb);
@@ -427,6 +458,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
           }
           ngr[i] = div_rcp(refractivity(pp, tt) - n2, h, 1. / h);
           xh[i] -= h;
+        }
         }
       }
       double ex1[3];
@@ -1038,6 +1070,7 @@ struct LosRing {
   int *npr;
   double *tsurf;
   int nfield, RB, r, nc;
+  int shift;               // lanes per ray in the tracer wavefront = 1 << shift (ray slot = lane >> shift)
   __device__ __forceinline__ double &at(int field, int ip) const { return ring[((ip & (PEN_RING - 1)) * nfield + field) * RB + r]; }
   __device__ __forceinline__ size_t field_stride() const { return (size_t)RB; }
   __device__ __forceinline__ void begin_point(int ip) const {   // the slot still holds point ip - PEN_RING
@@ -1052,7 +1085,10 @@ struct LosRing {
     unsigned long long gone = running & ~cur;
     running = cur;
     if (first_active_lane()) {
-      for (; gone; gone &= gone - 1) st_rel(&npr[__ffsll((long long)gone) - 1], np + 2);
+      for (; gone; gone &= gone - 1) {
+        int const l = __ffsll((long long)gone) - 1;
+        if ((l & ((1 << shift) - 1)) == 0) st_rel(&npr[l >> shift], np + 2);
+      }
       st_rel(&ctl->cnt_trace, np);
     }
   }
@@ -1060,10 +1096,13 @@ struct LosRing {
     tsurf[r] = ts;
     st_rel(&npr[r], n + 1);
   }
-  __device__ __forceinline__ void never_enter(unsigned long long mask) {   // lane number == ray slot in wave 0
+  __device__ __forceinline__ void never_enter(unsigned long long mask) {   // lane number >> shift == ray slot in wave 0
     running = __ballot(1) & ~mask;
     if (first_active_lane())
-      for (; mask; mask &= mask - 1) st_rel(&npr[__ffsll((long long)mask) - 1], 1);
+      for (; mask; mask &= mask - 1) {
+        int const l = __ffsll((long long)mask) - 1;
+        if ((l & ((1 << shift) - 1)) == 0) st_rel(&npr[l >> shift], 1);
+      }
   }
   unsigned long long running;
 };
@@ -1093,7 +1132,7 @@ __device__ __forceinline__ int slice_start(double const *__restrict__ atm_time, 
 // the workgroup's rays (time, z, lon, lat, p, T, q[], k[], ln-p slope), copied there when all its rays use the same
 // slice.  The tracer's per-step profile gathers (a chain of dependent loads at L2 latency when one wave per SIMD
 // has nothing to hide them behind) then stay inside the CU.  Same numbers from another place: same results.
-template <bool WARM>
+template <bool WARM, bool QUAD>
 __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chunk_t c, int RB, int NE, int NC, int atm_cap) {
   __shared__ double tr_sh[15][64];
   __shared__ PenCtl ctl;
@@ -1170,18 +1209,22 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
   }
 
   if (wave == 0) {
-    // ---- tracer ----
-    if (lane < nray) {
-      long const ray = c.first + ray0 + lane;
-      LosRing L{ring, &ctl, npr, tsurf, nfield, RB, lane, NC, 0ull};
-      TraceResult const t = trace_ray(vt, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray], c.geom[4][ray],
-                                      c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
-      if (c.np_out) c.np_out[ray] = t.np;
-      c.tp[0][ray] = t.tpz;
-      c.tp[1][ray] = t.tplon;
-      c.tp[2][ray] = t.tplat;
-      tsurf[lane] = t.tsurf;
-      st_rel(&npr[lane], t.np + 1);          // also the rays that never entered the atmosphere or ran into NLOS
+    // ---- tracer ----  (QUAD: four lanes per ray, RB <= 16)
+    constexpr int SH = QUAD ? 2 : 0;
+    int const slot = lane >> SH;
+    if (slot < nray) {
+      long const ray = c.first + ray0 + slot;
+      LosRing L{ring, &ctl, npr, tsurf, nfield, RB, slot, NC, SH, 0ull};
+      TraceResult const t = trace_ray<LosRing, QUAD>(vt, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray],
+                                                     c.geom[4][ray], c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
+      if ((lane & ((1 << SH) - 1)) == 0) {
+        if (c.np_out) c.np_out[ray] = t.np;
+        c.tp[0][ray] = t.tpz;
+        c.tp[1][ray] = t.tplon;
+        c.tp[2][ray] = t.tplat;
+        tsurf[slot] = t.tsurf;
+        st_rel(&npr[slot], t.np + 1);        // also the rays that never entered the atmosphere or ran into NLOS
+      }
     }
     if (lane == 0) {                         // every ray is through: its point count governs from here on
       int m = 0;
@@ -1605,12 +1648,21 @@ extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int
   long const lds_all = lds + 8L * (7 + v->ng + v->nw) * atm_cap;
   static bool raised = false;      // dynamic LDS beyond 64 KB needs the attribute once per kernel
   if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     raised = true;
   }
-  if (v->sorted_tables) hipLaunchKernelGGL(jur_pencil_kernel<true>, grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
-  else hipLaunchKernelGGL(jur_pencil_kernel<false>, grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
+  // up to 16 rays per workgroup the tracer wavefront has four lanes per ray: one refraction probe each
+  bool const quad = RB <= 16 && !getenv("JUR_PENCIL_NO_QUAD");
+  if (v->sorted_tables) {
+    if (quad) hipLaunchKernelGGL((jur_pencil_kernel<true, true>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
+    else hipLaunchKernelGGL((jur_pencil_kernel<true, false>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
+  } else {
+    if (quad) hipLaunchKernelGGL((jur_pencil_kernel<false, true>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
+    else hipLaunchKernelGGL((jur_pencil_kernel<false, false>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
+  }
   return (int)hipGetLastError();
 }
 
