@@ -797,6 +797,55 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
   return (1. - c01(lip(l0.p, eps_p0, l1.p, eps_p1, p))) / tau;
 }
 
+// The same look-up by the four lanes of a quad, one (p, T) corner curve each (fused kernel: the chain's latency is
+// what counts there, and the four curve searches + interpolations are its longest part).  All four lanes hold the
+// chain's inputs and run the bracket searches redundantly; lane q takes curve q = 2 * level + temperature side,
+// the four curve emissivities are exchanged with DPP moves and every lane forms the blends -- the operations of
+// ega_eps_warm<false, false> in the same order, hence the same doubles.  State: br as there, ix = this lane's
+// position in its own curve.
+__device__ __forceinline__ double ega_eps_warm_quad(jur_view_t const &v, jur_int2 const pr, PairDesc<false> const &D, double tau,
+                                                    double t, double u, double p, unsigned &br, unsigned &ix) {
+  if (tau < 1e-9) return 0.;
+  if (pr.a < 2) return 1.;
+  void const *const ueb = v.ue;
+  int ipr = min((int)(br & 0xffu), pr.a - 2);
+  Lvl l0 = D.lvl(ipr), l1 = D.lvl(ipr + 1);
+  if ((p < l0.p) | (p >= l1.p)) {
+    while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = D.lvl(ipr); }
+    while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = D.lvl(ipr + 1); }
+  }
+  br = (br & ~0xffu) | (unsigned)ipr;
+  if (l0.nt < 2 || l1.nt < 2) return 1.;
+  unsigned const k0 = (unsigned)l0.c0, k1 = (unsigned)l1.c0;
+  int it0 = min((int)((br >> 8) & 0xffu), l0.nt - 2), it1 = min((int)((br >> 16) & 0xffu), l1.nt - 2);
+  Crv c00 = D.crv(k0 + it0), c01_ = D.crv(k0 + it0 + 1), c10 = D.crv(k1 + it1), c11 = D.crv(k1 + it1 + 1);
+  if ((t < c00.t) | (t >= c01_.t) | (t < c10.t) | (t >= c11.t)) {
+    while (t < c00.t && it0 > 0) { --it0; c01_ = c00; c00 = D.crv(k0 + it0); }
+    while (t >= c01_.t && it0 < l0.nt - 2) { ++it0; c00 = c01_; c01_ = D.crv(k0 + it0 + 1); }
+    while (t < c10.t && it1 > 0) { --it1; c11 = c10; c10 = D.crv(k1 + it1); }
+    while (t >= c11.t && it1 < l1.nt - 2) { ++it1; c10 = c11; c11 = D.crv(k1 + it1 + 1); }
+  }
+  br = (unsigned)ipr | ((unsigned)it0 << 8) | ((unsigned)it1 << 16);
+  if (c00.nu < 2 || c01_.nu < 2 || c10.nu < 2 || c11.nu < 2) return 1.;
+  int const q = threadIdx.x & 3;
+  Crv const mine = (q == 0) ? c00 : (q == 1) ? c01_ : (q == 2) ? c10 : c11;
+  unsigned const e0 = (unsigned)mine.e0;
+  int const n = mine.nu;
+  int i = min((int)ix, n - 2);
+  Ue a, b;
+  ld_pair(ueb, e0 + i, a, b);
+  double const eps = 1 - tau;
+  seek_curve<true>(ueb, e0, n, eps, i, a, b);
+  double const x = lip((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps) + u;
+  seek_curve<false>(ueb, e0, n, x, i, a, b);
+  double const ec = c01(lip((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, x));
+  ix = (unsigned)i;
+  double const ec0 = quad_bcast<0>(ec), ec1 = quad_bcast<1>(ec), ec2 = quad_bcast<2>(ec), ec3 = quad_bcast<3>(ec);
+  double const eps_p0 = c01(lip(c00.t, ec0, c01_.t, ec1, t));
+  double const eps_p1 = c01(lip(c10.t, ec2, c11.t, ec3, t));
+  return (1. - c01(lip(l0.p, eps_p0, l1.p, eps_p1, p))) / tau;
+}
+
 // ---------------------------------------------------------------------------------------
 // continua; the channel-only factors come precomputed in jur_chan_t
 // ---------------------------------------------------------------------------------------
@@ -1043,7 +1092,7 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
 __host__ __device__ inline long pen_lds_doubles(int nd, int ng, int nw, int RB) {
   long const npair = (long)nd * ng, nfield = JUR_F_K + nw + ng, nchain = RB * npair, nitem = (long)RB * nd;
   long const n1 = nchain > 0 ? nchain : 1;
-  return (long)PEN_RING * nfield * RB + (long)PEN_RINGE * (npair > 0 ? npair : 1) * RB + n1 + 2 * nitem + RB + (3 * n1 + RB + 1) / 2 + 2;
+  return (long)PEN_RING * nfield * RB + (long)PEN_RINGE * (npair > 0 ? npair : 1) * RB + n1 + 2 * nitem + RB + (5 * n1 + RB + 1) / 2 + 2;
 }
 
 struct PenCtl {            // LDS, one per workgroup
@@ -1147,14 +1196,13 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
   double *const c_tau = c_rad + nitem;
   double *const tsurf = c_tau + nitem;
   unsigned *const st_br = reinterpret_cast<unsigned *>(tsurf + RB);
-  unsigned *const st_ia = st_br + (nchain > 0 ? nchain : 1);
-  unsigned *const st_ib = st_ia + (nchain > 0 ? nchain : 1);
-  int *const npr = reinterpret_cast<int *>(st_ib + (nchain > 0 ? nchain : 1));
+  unsigned *const st_ix = st_br + (nchain > 0 ? nchain : 1);     // [chain][4]: curve positions (ia, ib packed in [0], [1] without quads)
+  int *const npr = reinterpret_cast<int *>(st_ix + 4 * (nchain > 0 ? nchain : 1));
   int const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   long const ray0 = (long)blockIdx.x * RB;                         // first slot of this workgroup
   int const nray = (int)((c.n - ray0 < RB) ? c.n - ray0 : RB);    // rays it really has
 
-  for (int i = tid; i < nchain; i += blockDim.x) { st_tau[i] = 1.0; st_br[i] = 0; st_ia[i] = 0; st_ib[i] = 0; }
+  for (int i = tid; i < nchain; i += blockDim.x) { st_tau[i] = 1.0; st_br[i] = 0; st_ix[4 * i] = st_ix[4 * i + 1] = st_ix[4 * i + 2] = st_ix[4 * i + 3] = 0; }
   for (int i = tid; i < nitem; i += blockDim.x) { c_rad[i] = 0.0; c_tau[i] = 1.0; }
   for (int i = tid; i < RB; i += blockDim.x) { npr[i] = (i < nray) ? 0 : 1; tsurf[i] = -999; }   // 1: through, no points
   if (tid == 0) {
@@ -1233,8 +1281,10 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
       st_rel(&ctl.done, 1);
     }
   } else if (wave <= NE) {
-    // ---- emissivity growth: one chain per (ray, channel, gas) ----
-    int const w = wave - 1, nl = NE * 64, me = w * 64 + lane;
+    // ---- emissivity growth: one chain per (ray, channel, gas); with QUAD (sorted tables) a quad of lanes per
+    // chain, one corner curve each ----
+    constexpr int CS = (QUAD && WARM) ? 2 : 0;                  // lanes per chain = 1 << CS
+    int const w = wave - 1, nl = (NE * 64) >> CS, me = (w * 64 + lane) >> CS;
     PairDesc<false> D{v.lvl, v.crv, 0u, 0u, 0u, 0u};
     for (int ip = 0;; ++ip) {
       int const cnt = wait_point(&ctl, ip);
@@ -1253,10 +1303,14 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
         double const p = slot[JUR_F_P * RB + r], t = slot[JUR_F_T * RB + r], u = slot[(JUR_F_K + v.nw + g) * RB + r];
         double const tau_path = st_tau[e];
         double eps;
-        if constexpr (WARM) {
-          unsigned br = st_br[e], ia = st_ia[e], ib = st_ib[e];
+        if constexpr (WARM && QUAD) {
+          unsigned br = st_br[e], ix = st_ix[4 * e + (lane & 3)];
+          eps = ega_eps_warm_quad(v, pd, D, tau_path, t, u, p, br, ix);
+          st_br[e] = br; st_ix[4 * e + (lane & 3)] = ix;
+        } else if constexpr (WARM) {
+          unsigned br = st_br[e], ia = st_ix[4 * e], ib = st_ix[4 * e + 1];
           eps = ega_eps_warm<false, false>(v, pd, D, tau_path, t, u, p, br, ia, ib);
-          st_br[e] = br; st_ia[e] = ia; st_ib[e] = ib;
+          st_br[e] = br; st_ix[4 * e] = ia; st_ix[4 * e + 1] = ib;
         } else eps = ega_eps_exact<false>(v, pd, D, tau_path, t, u, p);
         st_tau[e] = tau_path * eps;
         eslot[pr * RB + r] = eps;
@@ -1639,7 +1693,10 @@ extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int
   long const lds = jurk_pencil_lds_bytes(v, RB);
   if (RB < 1 || RB > 64 || lds <= 0) return (int)hipErrorInvalidValue;
   int const npair = v->nd * v->ng;
-  int NE = (RB * npair + 63) / 64, NC = (RB * v->nd + 63) / 64;
+  // up to 16 rays per workgroup the tracer wavefront has four lanes per ray (one refraction probe each) and, for
+  // sorted tables, every chain four lanes (one corner curve each)
+  bool const quad = RB <= 16 && !getenv("JUR_PENCIL_NO_QUAD");
+  int NE = (RB * npair * ((quad && v->sorted_tables) ? 4 : 1) + 63) / 64, NC = (RB * v->nd + 63) / 64;
   NE = NE < 1 ? 1 : (NE > PEN_MAXE ? PEN_MAXE : NE);
   NC = NC < 1 ? 1 : (NC > PEN_MAXC ? PEN_MAXC : NC);
   dim3 const grid((unsigned)((c->n + RB - 1) / RB)), block((unsigned)(64 * (1 + NE + NC)));
@@ -1654,8 +1711,6 @@ extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int
     (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     raised = true;
   }
-  // up to 16 rays per workgroup the tracer wavefront has four lanes per ray: one refraction probe each
-  bool const quad = RB <= 16 && !getenv("JUR_PENCIL_NO_QUAD");
   if (v->sorted_tables) {
     if (quad) hipLaunchKernelGGL((jur_pencil_kernel<true, true>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
     else hipLaunchKernelGGL((jur_pencil_kernel<true, false>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
