@@ -35,14 +35,14 @@ for name, case in (("limb_66", common.limb_case()), ("nadir_90", common.nadir_ca
     res = {"batched": timed(m, case.geom)}
     m.set_pencil(1 << 20, 0)
     res["fused"] = timed(m, case.geom)
-    if name == "limb_1088":
+    if name in ("limb_1088", "limb_1088_4ch_64prof"):
         res["fused_rays_per_group"] = {}
         for rb in (1, 2, 4, 8, 16):
             m.set_pencil(1 << 20, rb)
             res["fused_rays_per_group"][rb] = timed(m, case.geom, n=10)["ms_per_call"]
         big = {}
         for nr in (272, 544, 2176, 4352, 8704, 17408):
-            g = synth.limb_geometry(nr, seed=2)
+            g = synth.limb_geometry(nr, seed=2, nprofiles=64 if "64prof" in name else 1)
             row = {}
             m.set_pencil(0)
             row["batched_ms"] = timed(m, g, n=5)["ms_per_call"]
