@@ -576,10 +576,20 @@ int jur_model_reserve(jur_model_t *m, long nr) {
  * (too many rays, or more (channel, gas) chains per ray than the LDS rings hold). */
 static int pencil_rays_per_group(jur_model_t const *m, long nr) {
   if (m->pencil_rays <= 0 || nr > m->pencil_rays) return 0;
+  long const npair = (long)m->view.nd * (m->view.ng > 0 ? m->view.ng : 1);
   int rb = m->pencil_rb;
-  if (rb <= 0) {   /* measured (tools/bench_small.py): fastest with about 136 workgroups' worth of tracer wavefronts per call */
-    rb = 1;
-    while (rb < 16 && nr > 136L * rb) rb *= 2;
+  if (rb <= 0) {
+    /* Measured (tools/bench_small.py, profiles/r02_small_call_latency.json): with 10 chains per ray the fused kernel
+     * beats the batched ones up to ~10 000 rays, with 20 up to ~4 500: the chains' look-ups (four lanes each) must
+     * keep up with the tracer.  Rays per workgroup: about 136 workgroups per call and at most 8 rays for up to 12
+     * chains per ray, 1 or 4 rays for up to 25, fewer beyond, so that a workgroup's chain lanes stay within its
+     * eight look-up wavefronts. */
+    if (nr * npair > 100000) return 0;
+    if (npair <= 12) {
+      rb = 1;
+      while (rb < 8 && nr > 136L * rb) rb *= 2;
+    } else if (npair <= 25) rb = (nr <= 600) ? 1 : 4;      /* (2 rays per workgroup measured slower than 1 and 4) */
+    else rb = (npair <= 50 && nr > 600) ? 2 : 1;
   }
   if (rb > 64) rb = 64;
   while (rb > 1 && jurk_pencil_lds_bytes(&m->view, rb) <= 0) rb /= 2;
