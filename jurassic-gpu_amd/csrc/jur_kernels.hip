@@ -1065,9 +1065,11 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
 //
 // A workgroup owns RB rays.  Its wavefronts take roles and hand the line of sight from one to the next through
 // LDS, point by point, as it is being traced:
-//   wave 0              traces the rays, one lane each (trace_ray), into a ring of LOS points in LDS;
-//   waves 1 .. NE       one lane per (ray, channel, gas) chain: the emissivity-growth recurrence of the points the
-//                       tracer has released, search state and accumulated transmittance of the chain in LDS;
+//   wave 0              traces the rays (trace_ray) into a ring of LOS points in LDS -- up to 16 rays per workgroup
+//                       with a quad of lanes per ray, one refraction probe each;
+//   waves 1 .. NE       the emissivity-growth recurrence of every (ray, channel, gas) chain on the points the tracer
+//                       has released -- sorted tables: a quad of lanes per chain, one (p, T) corner curve each
+//                       (ega_eps_warm_quad); search state and accumulated transmittance of the chain in LDS;
 //                       segment transmittances go to a second ring;
 //   waves NE+1 .. +NC   one lane per (ray, channel): continua, product over the gases, Planck source, radiance
 //                       update, epilogue -- the body of jur_combine_kernel.
