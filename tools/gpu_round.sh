@@ -25,7 +25,9 @@ for w in $WHAT; do
     micro) step microbench_build 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-result -o /tmp/microbench_valu tools/microbench_valu.hip
            TAIL=1 step microbench 120 /tmp/microbench_valu ;;
     pmc)   PMC_SHORT=${PMC_SHORT-1} step pmc 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_pmc --rays 1000000 --steps 1 --warmup 0
-           step pmc_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc limb_1e6 1000000 gpurun_out/${TAG}_pmc_current.json ;;
+           step pmc_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc limb_1e6 1000000 gpurun_out/${TAG}_pmc_current.json
+           PMC_SHORT=1 step pmc_nadir 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_pmc_nadir --workload nadir_1e5 --steps 1 --warmup 0
+           step pmc_nadir_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_nadir nadir_1e5 100000 gpurun_out/${TAG}_pmc_current.json ;;
     lanesmode) for md in "JUR_NO_ZERO_COPY=1" "GPU_MAX_HW_QUEUES=8" "JUR_PENCIL_RAYS=0"; do echo "$md"; EXTRA_ENV="env $md" CALLS=16 bash tools/run_lanes_bench.sh 2>&1 | grep threads; done > $OUTDIR/${TAG}_lanesmode.log 2>&1; cat $OUTDIR/${TAG}_lanesmode.log ;;
     torchrun1) TAIL=1 step bench_torchrun1 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --no-cpu-baseline --no-host-inclusive ;;
     wide) TAIL=1 JUR_ND=2378 JUR_NG=3 JUR_SUFFIX=_nd2378 step wide 900 python3 tools/bench_wide.py 4096 ;;
