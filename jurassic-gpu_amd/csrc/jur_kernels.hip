@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
     auto L = [&](int field) { return ldg<double>(los + (size_t)field * fs + o, r); };
     double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
     double beta_ds = L(f_k) * ds;
-    double const rt = 1. / t;
+    double const rt = (do_h2o | do_n2 | do_o2) ? 1. / t : 0.;      // (uniform: only the continua that divide by T)
     if (do_co2) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
     if (do_h2o) beta_ds += ctm_h2o(ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
     if (do_n2) beta_ds += ctm_n2(ch, p, t, rt) * ds;
@@ -1337,7 +1337,7 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
         auto L = [&](int field) { return slot[field * RB + r]; };
         double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
         double beta_ds = L(JUR_F_K + ch.window) * ds;
-        double const rt = 1. / t;
+        double const rt = ((v.fourbit & 7) && (ch.h2o_on | ch.n2_on | ch.o2_on)) ? 1. / t : 0.;
         if ((v.fourbit & 8) && ch.co2_on) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
         if ((v.fourbit & 4) && ch.h2o_on) beta_ds += ctm_h2o(ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
         if ((v.fourbit & 2) && ch.n2_on) beta_ds += ctm_n2(ch, p, t, rt) * ds;
