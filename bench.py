@@ -283,10 +283,17 @@ def main(argv):
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the library has no CPU path")
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        # rehearsal on a box with fewer GPUs than ranks (JUR_BENCH_REHEARSAL=1): every rank on a device it shares,
+        # gloo instead of RCCL (which refuses two ranks on one device); the line says so and is not a measurement
+        rehearsal = os.environ.get("JUR_BENCH_REHEARSAL") == "1"
+        gpu = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+        torch.cuda.set_device(gpu)
+        dev = torch.device("cuda", gpu)
         if use_dist:
-            dist.init_process_group("nccl", device_id=dev)
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
     if use_dist and dist.get_world_size() != args.gpus:
         raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
@@ -315,7 +322,7 @@ def main(argv):
             d_rad.copy_(forward(geom_local))
     else:
         from jurassic_hip import lib
-        model = lib.Model(case.ctl, case.lib_tables(), device=local_rank)
+        model = lib.Model(case.ctl, case.lib_tables(), device=dev.index)
         model.set_atm(case.atm)
         d_geom = torch.from_numpy(np.ascontiguousarray(case.geom.T)).to(dev)       # [7][nr]
         d_rad = torch.zeros((nrays, nd), dtype=torch.float64, device=dev)
@@ -435,6 +442,8 @@ def main(argv):
         }
         if verified:
             out["gather_check"] = verified
+        if os.environ.get("JUR_BENCH_REHEARSAL") == "1" and not dry:
+            out["rehearsal"] = "ranks share GPUs, gloo instead of RCCL: exercises the N-rank code path, measures nothing"
         if dry:
             out["dry_run"] = True
         else:
