@@ -342,6 +342,8 @@ def main(argv):
     def full_step():
         step()
         if use_dist:                # per-detector radiances to rank 0: each peer sends its block straight to the root
+            if not dry and os.environ.get("JUR_BENCH_REHEARSAL") == "1":
+                torch.cuda.synchronize()    # gloo is not ordered behind the compute stream the way RCCL is
             shard.gather_rows(d_rad, counts, dst=0, out=gathered)
 
     def fence():
