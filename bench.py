@@ -203,7 +203,8 @@ def roofline_block(workload, kms, nrays_step, steps, sum_np, shape, ab):
     LOS point total.  algorithmic_frac: SURVEY 8d's byte count of the REFERENCE algorithm (no cache credit)
     over the same duration -- kept for comparison, exceeds 1 because warm-started searches replace most probes."""
     ng, nd, nw, npair_tab, ng_tab = shape
-    pmc, why = load_pmc(workload)
+    # the sharded 1e7-ray set is the 1e6-ray workload's ray distribution at another size: its counters scale by rays
+    pmc, why = load_pmc("limb_1e6" if workload.startswith("limb") else workload)
     compulsory = {  # bytes per LOS point (ray, point): reads + writes each kernel must do
         "trace": 8.0 * (4 + nw + ng),                                   # writes p, T, ds, q_H2O, k[nw], u[ng]
         "ega": 8.0 * (2 + ng_tab + npair_tab),                          # reads p, T, u[g]; writes one double per pair
