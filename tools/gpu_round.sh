@@ -49,6 +49,7 @@ for w in $WHAT; do
     ab) TAIL=20 step ab 900 bash tools/ab_env.sh $AB ;;
     fuzz) TAIL=3 step fuzz 1100 python3 tools/fuzz_parity.py ${FUZZ:-3000 400} ;;
     rehearse2) TAIL=1 JUR_BENCH_REHEARSAL=1 step rehearse2 900 python3 bench.py --gpus 2 --rays 600000 --steps 2 --warmup 1 ;;
+    jac) TAIL=1 step jacobian 600 python3 tools/bench_jacobian.py ;;
     conc) TAIL=1 step concurrent 300 python3 tools/bench_concurrent.py ;;
     pencil) step pencil_tests 600 python3 -m pytest tests/test_pencil_gpu.py -q -p no:cacheprovider ;;
     lanestrace) D=$(mktemp -d); ( cd $D && python3 - <<PY
