@@ -576,23 +576,6 @@ __device__ __forceinline__ void ld_pair(void const *__restrict__ ue, unsigned id
 
 template <bool ON_EPS>
 __device__ __forceinline__ double ukey(Ue const &e) { return ON_EPS ? (double)e.eps : (double)e.u; }
-#ifndef JUR_EGA_DBL
-#define JUR_EGA_DBL 0
-#endif
-// experiment (JUR_EGA_DBL=1): a bracket's two entries kept as doubles once loaded, instead of converting the fp32
-// fields at every use
-struct UeD {
-  double u, eps;
-  __device__ __forceinline__ UeD() {}
-  __device__ __forceinline__ UeD(Ue const &e) : u((double)e.u), eps((double)e.eps) {}
-};
-template <bool ON_EPS>
-__device__ __forceinline__ double ukey(UeD const &e) { return ON_EPS ? e.eps : e.u; }
-__device__ __forceinline__ void ld_pair(void const *__restrict__ ue, unsigned idx, UeD &a, UeD &b) {
-  Ue fa, fb;
-  ld_pair(ue, idx, fa, fb);
-  a = UeD(fa); b = UeD(fb);
-}
 
 // EXACT: the reference's bisection (locate_tbl_id, jr_common.h:116-125) on curve [e0, e0+n)
 template <bool ON_EPS>
@@ -608,13 +591,13 @@ __device__ __forceinline__ int bisect_curve(void const *__restrict__ ue, unsigne
 // WARM: move bracket i (entries a = e[i], b = e[i+1] already loaded) to the one that holds x:
 // key(e[i]) <= x < key(e[i+1]), clamped to [0, n-2].  One step is the common case; otherwise
 // gallop, then bisect inside the gap.
-template <bool ON_EPS, class E>
-__device__ __forceinline__ void seek_curve(void const *__restrict__ ue, unsigned e0, int n, double x, int &i, E &a, E &b) {
+template <bool ON_EPS>
+__device__ __forceinline__ void seek_curve(void const *__restrict__ ue, unsigned e0, int n, double x, int &i, Ue &a, Ue &b) {
   bool const up = x >= ukey<ON_EPS>(b), down = x < ukey<ON_EPS>(a);
   if (!(up | down)) return;                      // one test for the common case: still in the bracket
   if (up) {
     if (i >= n - 2) return;
-    E const c = E(ld_ue(ue, e0 + i + 2));
+    Ue const c = ld_ue(ue, e0 + i + 2);
     if (i + 2 >= n - 1 || ukey<ON_EPS>(c) > x) { ++i; a = b; b = c; return; }
     int lo = i + 2, hi, step = 2;
     for (;;) {
@@ -633,7 +616,7 @@ __device__ __forceinline__ void seek_curve(void const *__restrict__ ue, unsigned
    
   } else {
     if (i <= 0) return;
-    E const c = E(ld_ue(ue, e0 + i - 1));
+    Ue const c = ld_ue(ue, e0 + i - 1);
     if (i - 1 <= 0 || ukey<ON_EPS>(c) <= x) { --i; b = a; a = c; return; }
     int hi = i - 1, lo, step = 2;
     for (;;) {
@@ -781,11 +764,7 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
     unsigned const e0[2] = {(unsigned)ca.e0, (unsigned)cb.e0};
     int const n[2] = {ca.nu, cb.nu};
     int i[2] = {(int)(packed & 0xffffu), (int)(packed >> 16)};
-#if JUR_EGA_DBL
-    UeD a[2], b[2];
-#else
     Ue a[2], b[2];
-#endif
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       i[k] = min(i[k], n[k] - 2);
