@@ -28,4 +28,6 @@ for seed in range(first, first + count):
     T.assert_parity(out, ref)
     fin = np.isfinite(ref["rad"])
     worst = max(worst, float(common.rel_err(out["rad"][fin], ref["rad"][fin]).max()))
+    if (seed - first) % 100 == 99:
+        print("... seeds %d..%d ok, worst so far %.3e" % (first, seed, worst), flush=True)
 print("FUZZ_OK seeds %d..%d, %d skipped (NLOS overflow), worst relative radiance deviation %.3e" % (first, first + count - 1, skipped, worst))

@@ -47,7 +47,7 @@ for w in $WHAT; do
     cmpbuilds) TAIL=2 step compare_builds 600 python3 tools/compare_builds.py jurassic-gpu_amd/libjurassic_hip_prev.so jurassic-gpu_amd/libjurassic_hip.so 300000 ;;
     kat) step kat 600 python3 -m pytest tests/test_kat_gpu.py -q -p no:cacheprovider ;;
     ab) TAIL=20 step ab 900 bash tools/ab_env.sh $AB ;;
-    fuzz) TAIL=3 step fuzz 1100 python3 tools/fuzz_parity.py ${FUZZ:-3000 400} ;;
+    fuzz) echo "== fuzz"; timeout -k 10 1100 python3 tools/fuzz_parity.py ${FUZZ:-3000 400} 2>&1 | tee $OUTDIR/${TAG}_fuzz.log | grep -v "^Read\|^Init" ;;
     rehearse2) TAIL=1 JUR_BENCH_REHEARSAL=1 step rehearse2 900 python3 bench.py --gpus 2 --rays 600000 --steps 2 --warmup 1 ;;
     abso) TAIL=20 step abso 900 bash tools/ab_env.sh "JURASSIC_HIP_SO=$GRAFT_REPO_ROOT/jurassic-gpu_amd/libjurassic_hip.so" "JURASSIC_HIP_SO=$GRAFT_REPO_ROOT/jurassic-gpu_amd/libjurassic_hip$ABSUF.so"
           TAIL=2 step abso_cmp 600 python3 tools/compare_builds.py jurassic-gpu_amd/libjurassic_hip.so jurassic-gpu_amd/libjurassic_hip$ABSUF.so 300000 ;;
