@@ -379,7 +379,8 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
       {  // remaining quantities on the same bracket (jr_common.h:557-567)
         double const za = v.atm_z[ia], zb = v.atm_z[ia + 1];
         double const kt = JUR_BOLTZMANN * t, rkt = 1. / kt;   // one division for all emitters' columns (div_rcp)
-        for (int ig = 0; ig < v.ng; ig++) {
+        // (QUAD: the four lanes of the ray share the emitters' columns between them; nobody in the tracer reads them back)
+        for (int ig = QUAD ? (int)(threadIdx.x & 3) : 0; ig < v.ng; ig += QUAD ? 4 : 1) {
           double const *q = v.atm_q + (size_t)ig * v.atm_np;
           double qv;
           if (zdir) qv = lip_rcp(za, q[ia], zb, q[ia + 1], z, rdz); else qv = lip(za, q[ia], zb, q[ia + 1], z);
