@@ -1685,7 +1685,8 @@ extern "C" long jurk_pencil_lds_bytes(jur_view_t const *v, int RB) {
 // room for the profile slab: the longest slice of the atmosphere, if that stays inside 32 KB
 static int pencil_atm_cap(jur_view_t const *v) {
   long const nrow = 7 + v->ng + v->nw;
-  if (!v->atm_sorted || v->atm_maxslice < 2 || getenv("JUR_PENCIL_NO_ATM_LDS")) return 0;
+  static int const off = getenv("JUR_PENCIL_NO_ATM_LDS") ? 1 : 0;      // A/B switch, read once
+  if (!v->atm_sorted || v->atm_maxslice < 2 || off) return 0;
   return (nrow * v->atm_maxslice * 8 <= 32 * 1024) ? v->atm_maxslice : 0;
 }
 
@@ -1696,7 +1697,8 @@ extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int
   int const npair = v->nd * v->ng;
   // up to 16 rays per workgroup the tracer wavefront has four lanes per ray (one refraction probe each) and, for
   // sorted tables, every chain four lanes (one corner curve each)
-  bool const quad = RB <= 16 && !getenv("JUR_PENCIL_NO_QUAD");
+  static bool const no_quad = getenv("JUR_PENCIL_NO_QUAD") != nullptr;   // A/B switch, read once
+  bool const quad = RB <= 16 && !no_quad;
   int NE = (RB * npair * ((quad && v->sorted_tables) ? 4 : 1) + 63) / 64, NC = (RB * v->nd + 63) / 64;
   NE = NE < 1 ? 1 : (NE > PEN_MAXE ? PEN_MAXE : NE);
   NC = NC < 1 ? 1 : (NC > PEN_MAXC ? PEN_MAXC : NC);

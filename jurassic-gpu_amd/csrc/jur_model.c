@@ -788,7 +788,9 @@ int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double
     int *const h_np = (int *)(h_tp + 3 * N);
     for (int k = 0; k < 7; k++) memcpy(h_geom + k * N, geom[k], sizeof(double) * N);
     memcpy(h_rad, rad, sizeof(double) * nrd);
-    if (pencil_rays_per_group(m, nr) > 0 && !getenv("JUR_NO_ZERO_COPY")) {
+    static int no_zero_copy = -1;                /* A/B switch, read once */
+    if (no_zero_copy < 0) no_zero_copy = getenv("JUR_NO_ZERO_COPY") ? 1 : 0;
+    if (pencil_rays_per_group(m, nr) > 0 && !no_zero_copy) {
       /* The fused kernel reads the geometry from the pinned image and writes its results there itself (a few
        * hundred KB over PCIe at the two ends of the kernel): ONE launch and one wait per call.  With copy
        * commands around the kernel, concurrent callers (the lanes of the drop-in entry) were serialised by the
