@@ -33,6 +33,11 @@ void formod_pencil(ctl_t const *ctl, atm_t *atm, obs_t *obs, int const ir);
  * no-op when ctl->fov is "-"; host code */
 void formod_fov(ctl_t const *ctl, obs_t *obs);
 
+/* regridding of an atmosphere onto the points of another (jurassic.h:581-585, jurassic.c:675-683): dest->p, t, q, k
+ * at dest's z / lon / lat from src by ctl->ip = 1 (one profile), 2 (the nearest two profiles of a satellite
+ * track) or 3 (distance-weighted mean of a point cloud, ctl->cx / ctl->cz); GPU, device ctl->MPIlocalrank */
+void intpol_atm(ctl_t *ctl, atm_t *atm_dest, atm_t *atm_src);
+
 /* ---- (2) additive --------------------------------------------------------- */
 enum {
   JUR_OK = 0,
@@ -149,6 +154,10 @@ int  jur_fov_apply(int nd, long nr, double const *time, double const *vpz, doubl
  * arrays.  Returns after the work on `stream` has finished; JUR_EINVAL if a ray is alone in its scan. */
 int  jur_fov_apply_device(jur_model_t *m, long nr, double const *d_time, double const *d_vpz, double *d_rad,
                           double *d_tau, int n, double const *dz, double const *w, void *stream);
+
+/* intpol_atm with an error code instead of exit(): JUR_EINVAL for what upstream aborts on (profiles of one point,
+ * profiles more than 10 degrees apart, unknown IP).  One lane per destination point on `device`. */
+int  jur_intpol_atm(ctl_t const *ctl, atm_t *dest, atm_t const *src, int device);
 
 /* Allocate the workspace for calls of up to nr rays now.  jur_formod_device allocates lazily on
  * first use; after jur_model_reserve (or one call of the same size) it only enqueues kernels on

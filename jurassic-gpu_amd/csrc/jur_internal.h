@@ -109,6 +109,10 @@ int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int RB, void *
 int jurk_launch_fov(long nr, int nd, double const *time, double const *vpz, double const *rad0, double const *tau0, double *rad,
                     double *tau, long ld, int n, double const *dz, double const *w, int *status, void *stream);
 
+/* atmosphere regridding (intpol_atm): device rows as documented at jur_intpol_kernel */
+int jurk_launch_intpol(int ip, int ng, int nw, int ns, int nd_, int nx, double cx, double cz, double const *src, double const *x1,
+                       int const *idx, int const *nz, double const *dst, double const *x0, double *out, void *stream);
+
 /* known-answer hooks (tests): device functions on arrays, see jurassic_hip.h */
 int jurk_kat_ega(jur_view_t const *v, int g, int d, long n, double const *tau, double const *t, double const *u, double const *p,
                  int mode, int chain, double *out, void *stream);

@@ -1489,6 +1489,88 @@ __global__ __launch_bounds__(256) void jur_fov_kernel(long nr, int nd, double co
 }
 
 // ---------------------------------------------------------------------------------------
+// atmosphere regridding (intpol_atm, jurassic.c:675-804): the step in front of the path for atmospheres that
+// are not one profile.  One lane per destination point; ip = 1 one profile, 2 the nearest two profiles of a
+// track, 3 the distance-weighted mean of a point cloud.  The Cartesian positions of source and destination points
+// come from the host (they are what upstream caches), the kernel does the searches and the interpolation.
+// src rows: z, lon, lat, p, T, q[ng], k[nw], each [ns]; out rows: p, T, q[ng], k[nw], each [nd_].
+// ---------------------------------------------------------------------------------------
+struct IntpolArgs {
+  int ip, ng, nw, ns, nd_, nx;
+  double cx, cz;
+  double const *src;        // [5 + ng + nw][ns]
+  double const *x1;         // ip 2: [nx][3] profile positions; ip 3: [ns][3] point positions
+  int const *idx, *nz;      // ip 2: first point and length of every profile
+  double const *dst;        // [3][nd_]: z, lon, lat of the destination points
+  double const *x0;         // [nd_][3] their positions
+  double *out;              // [2 + ng + nw][nd_]
+};
+
+__device__ __forceinline__ double eip_dev(double x0, double y0, double x1, double y1, double x) {
+  if ((y0 > 0) && (y1 > 0)) return y0 * exp(log(y1 / y0) / (x1 - x0) * (x - x0));
+  return lip(x0, y0, x1, y1, x);
+}
+
+// intpol_atm_1d on source points [i0, i0 + n): row r of the source interpolated to z0
+__device__ __forceinline__ double ip1d(IntpolArgs const &a, int ipt, int row, double z0) {
+  double const *const z = a.src, *const y = a.src + (size_t)row * a.ns;
+  return (row == 3) ? eip_dev(z[ipt], y[ipt], z[ipt + 1], y[ipt + 1], z0) : lip(z[ipt], y[ipt], z[ipt + 1], y[ipt + 1], z0);
+}
+
+__global__ __launch_bounds__(128) void jur_intpol_kernel(IntpolArgs a) {
+  int const id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= a.nd_) return;
+  int const nrow = 2 + a.ng + a.nw;                       // p, T, q[], k[]: source rows 3 ..
+  double const z0 = a.dst[id], lat0 = a.dst[2 * (size_t)a.nd_ + id];
+  double const x0[3] = {a.x0[3 * (size_t)id], a.x0[3 * (size_t)id + 1], a.x0[3 * (size_t)id + 2]};
+  auto OUT = [&](int r) -> double & { return a.out[(size_t)r * a.nd_ + id]; };
+  if (a.ip == 1) {
+    int const ipt = locate_axis(a.src, a.ns, z0);
+    for (int r = 0; r < nrow; r++) OUT(r) = ip1d(a, ipt, 3 + r, z0);
+  } else if (a.ip == 2) {
+    double dhmin0 = 1e99, dhmin1 = 1e99;
+    int ix0 = 0, ix1 = 0;
+    double const *const lat = a.src + 2 * (size_t)a.ns;
+    for (int ix = 0; ix < a.nx; ix++)
+      if (fabs(lat0 - lat[a.idx[ix]]) <= 10) {
+        double const *const x1 = a.x1 + 3 * (size_t)ix;
+        double const dh = (x0[0] - x1[0]) * (x0[0] - x1[0]) + (x0[1] - x1[1]) * (x0[1] - x1[1]) + (x0[2] - x1[2]) * (x0[2] - x1[2]);
+        if (dh <= dhmin0) { dhmin1 = dhmin0; ix1 = ix0; dhmin0 = dh; ix0 = ix; }
+        else if (dh <= dhmin1) { dhmin1 = dh; ix1 = ix; }
+      }
+    int const i0 = a.idx[ix0] + locate_axis(a.src + a.idx[ix0], a.nz[ix0], z0);
+    int const i1 = a.idx[ix1] + locate_axis(a.src + a.idx[ix1], a.nz[ix1], z0);
+    double const *const xa = a.x1 + 3 * (size_t)ix0, *const xb = a.x1 + 3 * (size_t)ix1;
+    double const x2 = (xa[0] - xb[0]) * (xa[0] - xb[0]) + (xa[1] - xb[1]) * (xa[1] - xb[1]) + (xa[2] - xb[2]) * (xa[2] - xb[2]);
+    double const x = sqrt(x2);
+    double const r0 = (dhmin0 - dhmin1 + x2) / (2 * x);
+    double const r1 = x - r0;
+    double r;
+    if (r0 <= 0) r = 0;
+    else r = (r1 <= 0) ? 1 : r0 / (r0 + r1);
+    for (int k = 0; k < nrow; k++) OUT(k) = (1 - r) * ip1d(a, i0, 3 + k, z0) + r * ip1d(a, i1, 3 + k, z0);
+  } else {
+    double const rm2 = a.cx * a.cx;
+    double wsum = 0;
+    for (int r = 0; r < nrow; r++) OUT(r) = 0;
+    double const *const lat = a.src + 2 * (size_t)a.ns;
+    for (int ipt = 0; ipt < a.ns; ipt++) {
+      double const dz = fabs(a.src[ipt] - z0);
+      if (dz >= a.cz) continue;
+      if (fabs(lat[ipt] - lat0) * 111.13 >= a.cx) continue;
+      double const *const x1 = a.x1 + 3 * (size_t)ipt;
+      double const dx2 = (x0[0] - x1[0]) * (x0[0] - x1[0]) + (x0[1] - x1[1]) * (x0[1] - x1[1]) + (x0[2] - x1[2]) * (x0[2] - x1[2]);
+      if (dx2 >= rm2) continue;
+      double const w = (1 - dz / a.cz) * (rm2 - dx2) / (rm2 + dx2);
+      wsum += w;
+      for (int r = 0; r < nrow; r++) OUT(r) += w * a.src[(size_t)(3 + r) * a.ns + ipt];
+    }
+    if (wsum >= 1e-6) for (int r = 0; r < nrow; r++) OUT(r) /= wsum;
+    else for (int r = 0; r < nrow; r++) OUT(r) = __builtin_nan("");
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // known-answer hooks (tests): the device functions above on arrays of inputs, one element per lane,
 // so that each can be compared with its reference counterpart at thresholds and range edges
 // (jr_common.h:239 tau < 1e-9, :295 tau_gas > 1e-50, continuum windows :318,345,367,381, extrapolation
@@ -1730,5 +1812,14 @@ extern "C" int jurk_launch_fov(long nr, int nd, double const *time, double const
   long const total = nr * nd;
   hipLaunchKernelGGL(jur_fov_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nr, nd, time, vpz, rad0,
                      tau0, rad, tau, ld, n, dz, w, status);
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_launch_intpol(int ip, int ng, int nw, int ns, int nd_, int nx, double cx, double cz, double const *src,
+                                  double const *x1, int const *idx, int const *nz, double const *dst, double const *x0, double *out,
+                                  void *stream) {
+  if (nd_ <= 0) return 0;
+  IntpolArgs const a{ip, ng, nw, ns, nd_, nx, cx, cz, src, x1, idx, nz, dst, x0, out};
+  hipLaunchKernelGGL(jur_intpol_kernel, dim3((unsigned)((nd_ + 127) / 128)), dim3(128), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

@@ -52,6 +52,9 @@ def lib():
         L.jur_formod_host.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
         L.jur_curtis_godson_host.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), dp, dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
         L.jur_fov_apply_device.argtypes = [C.c_void_p, C.c_long] + [C.c_void_p] * 4 + [C.c_int, dp, dp, C.c_void_p]
+        L.jur_intpol_atm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.intpol_atm.argtypes = [C.c_void_p] * 3
+        L.intpol_atm.restype = None
         L.jur_host_alloc.restype = C.c_void_p
         L.jur_host_alloc.argtypes = [C.c_size_t]
         L.jur_host_free.argtypes = [C.c_void_p]
@@ -312,6 +315,11 @@ class Model:
 def formod(ctl, atm, obs):
     """Drop-in entry (reference CPUdrivers.c:179): tables from ctl.tblbase files."""
     lib().formod(C.byref(ctl), C.byref(atm), C.byref(obs))
+
+
+def intpol_atm(ctl, dest, src, device=0):
+    """Regrid src onto dest's points (reference intpol_atm, jurassic.c:675): fills dest.p, t, q, k."""
+    _chk(lib().jur_intpol_atm(C.byref(ctl), C.byref(dest), C.byref(src), device))
 
 
 def formod_fov(ctl, obs):

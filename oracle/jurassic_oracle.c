@@ -1054,6 +1054,111 @@ int orc_formod_fov(ctl_t const *ctl, obs_t *obs, int n, double const *dz, double
 }
 
 /* number of OpenMP threads the next calls use (0: leave as is); returns the current maximum */
+
+/* ------------------------------------------------------------------------ */
+/* atmosphere regridding, jurassic.c:675-804 (intpol_atm, intpol_atm_geo,     */
+/* intpol_atm_1d / 2d / 3d): the step in front of the path for atmospheres    */
+/* that are not one profile.  Returns 0, or the negative number of the         */
+/* upstream ERRMSG that would have ended the process.                          */
+/* ------------------------------------------------------------------------ */
+#define DIST2(a, b) ((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]))
+
+static void intpol_atm_1d(ctl_t const *ctl, atm_t const *atm, int idx0, int n, double z0, double *p, double *t, double *q,
+                          double *k) {
+  int const ip = idx0 + locate(&atm->z[idx0], n, z0);
+  *p = eip(atm->z[ip], atm->p[ip], atm->z[ip + 1], atm->p[ip + 1], z0);
+  *t = lip(atm->z[ip], atm->t[ip], atm->z[ip + 1], atm->t[ip + 1], z0);
+  for (int ig = 0; ig < ctl->ng; ig++) q[ig] = lip(atm->z[ip], atm->q[ig][ip], atm->z[ip + 1], atm->q[ig][ip + 1], z0);
+  for (int iw = 0; iw < ctl->nw; iw++) k[iw] = lip(atm->z[ip], atm->k[iw][ip], atm->z[ip + 1], atm->k[iw][ip + 1], z0);
+}
+
+int orc_intpol_atm(ctl_t const *ctl, atm_t *dest, atm_t const *src) {
+  static double x1[JUR_NP][3];
+  static int idx[JUR_NP], nz[JUR_NP];
+  int nx = 0;
+  if (ctl->ip == 2) {                                   /* profiles of a satellite track, :716-735 */
+    double lat1 = -999, lon1 = -999;
+    for (int ip = 0; ip < src->np; ip++) {
+      if ((src->lon[ip] != lon1) || (src->lat[ip] != lat1)) {
+        if ((++nx) > JUR_NP) return -1;
+        nz[nx - 1] = 0;
+        lon1 = src->lon[ip];
+        lat1 = src->lat[ip];
+        geo2cart(0, lon1, lat1, x1[nx - 1]);
+        idx[nx - 1] = ip;
+      }
+      ++nz[nx - 1];
+    }
+    for (int ix = 0; ix < nx; ix++) {
+      if (nz[ix] <= 1) return -2;
+      if ((ix > 0) && (fabs(src->lat[idx[ix - 1]] - src->lat[idx[ix]]) > 10)) return -3;
+    }
+  } else if (ctl->ip == 3) {
+    for (int ip = 0; ip < src->np; ip++) geo2cart(0, src->lon[ip], src->lat[ip], x1[ip]);
+  } else if (ctl->ip != 1) return -4;
+  for (int id = 0; id < dest->np; id++) {
+    double const z0 = dest->z[id], lon0 = dest->lon[id], lat0 = dest->lat[id];
+    double q[JUR_NG], k[JUR_NW], *p = &dest->p[id], *t = &dest->t[id];
+    if (ctl->ip == 1) intpol_atm_1d(ctl, src, 0, src->np, z0, p, t, q, k);
+    else if (ctl->ip == 2) {                            /* :737-766 */
+      double dhmin0 = 1e99, dhmin1 = 1e99, dlat = 10, k0[JUR_NW], k1[JUR_NW], p0, p1, q0[JUR_NG], q1[JUR_NG], r, t0, t1, x0[3];
+      int ix0 = 0, ix1 = 0;
+      geo2cart(0, lon0, lat0, x0);
+      for (int ix = 0; ix < nx; ix++)
+        if (fabs(lat0 - src->lat[idx[ix]]) <= dlat) {
+          double const dh = DIST2(x0, x1[ix]);
+          if (dh <= dhmin0) { dhmin1 = dhmin0; ix1 = ix0; dhmin0 = dh; ix0 = ix; }
+          else if (dh <= dhmin1) { dhmin1 = dh; ix1 = ix; }
+        }
+      intpol_atm_1d(ctl, src, idx[ix0], nz[ix0], z0, &p0, &t0, q0, k0);
+      intpol_atm_1d(ctl, src, idx[ix1], nz[ix1], z0, &p1, &t1, q1, k1);
+      double const x2 = DIST2(x1[ix0], x1[ix1]);
+      double const x = sqrt(x2);
+      double const r0 = (dhmin0 - dhmin1 + x2) / (2 * x);
+      double const r1 = x - r0;
+      if (r0 <= 0) r = 0;
+      else r = (r1 <= 0) ? 1 : r0 / (r0 + r1);
+      *p = (1 - r) * p0 + r * p1;
+      *t = (1 - r) * t0 + r * t1;
+      for (int ig = 0; ig < ctl->ng; ig++) q[ig] = (1 - r) * q0[ig] + r * q1[ig];
+      for (int iw = 0; iw < ctl->nw; iw++) k[iw] = (1 - r) * k0[iw] + r * k1[iw];
+    } else {                                            /* :768-804 */
+      double const rm2 = ctl->cx * ctl->cx;
+      double wsum = 0, x0[3];
+      *p = *t = 0.;
+      for (int ig = 0; ig < ctl->ng; ig++) q[ig] = 0;
+      for (int iw = 0; iw < ctl->nw; iw++) k[iw] = 0;
+      for (int ip = 0; ip < src->np; ip++) {
+        double const dz = fabs(src->z[ip] - z0);
+        if (dz >= ctl->cz) continue;
+        if (fabs(src->lat[ip] - lat0) * 111.13 >= ctl->cx) continue;
+        geo2cart(0, lon0, lat0, x0);
+        double const dx2 = DIST2(x0, x1[ip]);
+        if (dx2 >= rm2) continue;
+        double const w = (1 - dz / ctl->cz) * (rm2 - dx2) / (rm2 + dx2);
+        wsum += w;
+        *p += w * src->p[ip];
+        *t += w * src->t[ip];
+        for (int ig = 0; ig < ctl->ng; ig++) q[ig] += w * src->q[ig][ip];
+        for (int iw = 0; iw < ctl->nw; iw++) k[iw] += w * src->k[iw][ip];
+      }
+      if (wsum >= 1e-6) {
+        *p /= wsum;
+        *t /= wsum;
+        for (int ig = 0; ig < ctl->ng; ig++) q[ig] /= wsum;
+        for (int iw = 0; iw < ctl->nw; iw++) k[iw] /= wsum;
+      } else {
+        *p = *t = NAN;
+        for (int ig = 0; ig < ctl->ng; ig++) q[ig] = NAN;
+        for (int iw = 0; iw < ctl->nw; iw++) k[iw] = NAN;
+      }
+    }
+    for (int ig = 0; ig < ctl->ng; ig++) dest->q[ig][id] = q[ig];
+    for (int iw = 0; iw < ctl->nw; iw++) dest->k[iw][id] = k[iw];
+  }
+  return 0;
+}
+
 int orc_set_threads(int n) {
 #ifdef _OPENMP
   if (n > 0) omp_set_num_threads(n);

@@ -119,6 +119,10 @@ int orc_traceray(ctl_t const *ctl, atm_t const *atm, double const geom[7],
 void orc_hydrostatic(ctl_t const *ctl, atm_t *atm);
 /* Curtis-Godson means of one ray (jr_common.h:455-473): cgp/cgt/cgu are [JUR_NG... ng][JUR_NLOS]; returns np */
 int orc_set_threads(int n);
+/* intpol_atm (jurassic.c:675-804): dest->p, t, q, k at dest's z / lon / lat from src by ctl->ip = 1 (one profile),
+ * 2 (nearest two profiles of a track) or 3 (distance-weighted mean of a point cloud, ctl->cx, ctl->cz).
+ * 0, or -(number of the upstream error: 1 too many profiles, 2 ordering, 3 profile distance, 4 unknown IP). */
+int orc_intpol_atm(ctl_t const *ctl, atm_t *dest, atm_t const *src);
 int orc_formod_fov(ctl_t const *ctl, obs_t *obs, int n, double const *dz, double const *w);
 int orc_curtis_godson(ctl_t const *ctl, atm_t const *atm, double const geom[7], double *cgp, double *cgt, double *cgu);
 int  orc_find_emitter(ctl_t const *ctl, char const *name);

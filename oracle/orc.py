@@ -68,6 +68,7 @@ def lib():
         L.orc_atm2x.argtypes = [C.c_void_p, C.c_void_p, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_obs2y.restype = C.c_size_t
         L.orc_obs2y.argtypes = [C.c_void_p, C.c_void_p, dp]
+        L.orc_intpol_atm.argtypes = [C.c_void_p] * 3
         L.orc_kernel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dp, C.c_size_t, C.c_size_t]
         _lib = L
     return _lib
@@ -204,6 +205,11 @@ def kernel(ctl, atm, obs, tables):
     k = np.zeros((m, n))
     lib().orc_kernel(C.byref(ctl), C.byref(atm), C.byref(obs), tables.h, _p(k), m, n)
     return k
+
+
+def intpol_atm(ctl, dest, src):
+    """intpol_atm (jurassic.c:675-804) -> 0 or the negative number of the upstream error."""
+    return lib().orc_intpol_atm(C.byref(ctl), C.byref(dest), C.byref(src))
 
 
 def set_threads(n=0):
