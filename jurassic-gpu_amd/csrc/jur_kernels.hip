@@ -27,6 +27,7 @@
 //                         wavefronts hand the line of sight on through rings in LDS while it is being traced; the
 //                         same device functions as the three batched kernels, bit-identical results.
 //   jur_fov_kernel        field-of-view convolution of device arrays (formod_fov, jurassic.c:214-258).
+//   jur_intpol_kernel     regridding of a track / point-cloud atmosphere (intpol_atm, jurassic.c:675-804).
 //   jur_kat_*_kernel      known-answer hooks for tests: the device functions on arrays of inputs.
 //
 // All arithmetic is IEEE fp64 with the reference's operand order; tables are fp32 in memory.
