@@ -12,7 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _torch_first():
+    """PyTorch's ROCm wheel brings its own HIP runtime.  In a process that uses both torch and libjurassic_hip.so the
+    runtime that is loaded first serves both, and torch only finds its devices when that is its own: initialise
+    torch's side before any test loads the library (harmless without a GPU)."""
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
+
+
 def pytest_sessionstart(session):
+    _torch_first()
     """The built library and tools are not in the history (only in the working tree): build what is missing
     (hipcc cross-compiles without a GPU; about two minutes from scratch, nothing when up to date)."""
     pkg = os.path.join(ROOT, "jurassic-gpu_amd")
