@@ -51,6 +51,7 @@ for w in $WHAT; do
     rehearse2) TAIL=1 JUR_BENCH_REHEARSAL=1 step rehearse2 900 python3 bench.py --gpus 2 --rays 600000 --steps 2 --warmup 1 ;;
     abso) TAIL=20 step abso 900 bash tools/ab_env.sh "JURASSIC_HIP_SO=$GRAFT_REPO_ROOT/jurassic-gpu_amd/libjurassic_hip.so" "JURASSIC_HIP_SO=$GRAFT_REPO_ROOT/jurassic-gpu_amd/libjurassic_hip$ABSUF.so"
           TAIL=2 step abso_cmp 600 python3 tools/compare_builds.py jurassic-gpu_amd/libjurassic_hip.so jurassic-gpu_amd/libjurassic_hip$ABSUF.so 300000 ;;
+    abv) TAIL=30 step abv 1100 bash tools/ab_so.sh $ABV ;;
     jac) TAIL=1 step jacobian 600 python3 tools/bench_jacobian.py ;;
     conc) TAIL=1 step concurrent 300 python3 tools/bench_concurrent.py ;;
     pencil) step pencil_tests 600 python3 -m pytest tests/test_pencil_gpu.py -q -p no:cacheprovider ;;
