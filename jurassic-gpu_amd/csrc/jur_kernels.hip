@@ -1005,16 +1005,10 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   }
 }
 
-#ifndef JUR_COMBINE_PAIRS
-#define JUR_COMBINE_PAIRS 0
-#endif
-#ifndef JUR_COMBINE_WAVES
-#define JUR_COMBINE_WAVES 6
-#endif
 // jur_combine_kernel: one lane per ray, one channel per workgroup: continua, product of the gas
 // transmittances in the reference's order, Planck source, radiance update, epilogue.
 // 6 waves per SIMD: 18.2 ms per 1e6 limb rays against 20.6 ms at 4 and 20.4 ms at 7
-__global__ __launch_bounds__(256, JUR_COMBINE_WAVES) void jur_combine_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
+__global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
   int const nd = v.nd, ng = v.ng;
   // same XCD-aware order as jur_ega_kernel: the nd workgroups of one ray block follow each other
   // on one XCD and share the block's LOS rows in that L2
@@ -1046,9 +1040,7 @@ __global__ __launch_bounds__(256, JUR_COMBINE_WAVES) void jur_combine_kernel(jur
   int const np = c.np[r];
   unsigned has_table = 0;                              // gases with a table for this channel (uniform)
   for (int g = 0; g < ng && g < 32; g++) has_table |= (v.pair[g * nd + d].a >= 2 ? 1u : 0u) << g;
-  // what a segment contributes, apart from the two-line recurrence: independent from point to point
-  struct Seg { double tau_gas, beta_ds, src; };
-  auto segment = [&](int ip) -> Seg {
+  for (int ip = 0; ip < np; ++ip) {
     size_t const o = (size_t)ip * R;
     auto L = [&](int field) { return ldg<double>(los + (size_t)field * fs + o, r); };
     double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
@@ -1060,22 +1052,8 @@ __global__ __launch_bounds__(256, JUR_COMBINE_WAVES) void jur_combine_kernel(jur
     double tau_gas = 1.0;
     for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
       if ((has_table >> g) & 1u) tau_gas *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
-    return {tau_gas, beta_ds, planck_src(sr, t)};
-  };
-#if JUR_COMBINE_PAIRS
-  int ip = 0;
-  for (; ip + 1 < np; ip += 2) {                       // two segments' exp / tanh chains side by side
-    Seg const a = segment(ip), b = segment(ip + 1);
-    new_obs_step(a.tau_gas, a.beta_ds, a.src, rad, tau);
-    new_obs_step(b.tau_gas, b.beta_ds, b.src, rad, tau);
+    new_obs_step(tau_gas, beta_ds, planck_src(sr, t), rad, tau);
   }
-  if (ip < np) { Seg const a = segment(ip); new_obs_step(a.tau_gas, a.beta_ds, a.src, rad, tau); }
-#else
-  for (int ip = 0; ip < np; ++ip) {
-    Seg const a = segment(ip);
-    new_obs_step(a.tau_gas, a.beta_ds, a.src, rad, tau);
-  }
-#endif
   ray_epilogue(sr, ch.nu, c.tsurf[r], v.write_bbt, rad, tau);
   if (masked) rad = __builtin_nan("");
   c.rad[oidx] = rad;
