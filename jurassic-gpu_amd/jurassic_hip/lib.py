@@ -108,7 +108,10 @@ class Tables:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().jur_tables_free(self.h)
+            try:
+                lib().jur_tables_free(self.h)
+            except TypeError:          # interpreter shutdown
+                pass
             self.h = None
 
     def feed_rows(self, ig, id_, rows):
@@ -175,8 +178,11 @@ class HostBuffers:
 
     def close(self):
         self.geom = self.rad = self.tau = self.tp = self.np = None
-        for p in self._raw:
-            lib().jur_host_free(p)
+        for p in getattr(self, "_raw", []):
+            try:
+                lib().jur_host_free(p)
+            except TypeError:          # interpreter shutdown
+                pass
         self._raw = []
 
     __del__ = close
@@ -197,7 +203,10 @@ class Model:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().jur_model_destroy(self.h)
+            try:
+                lib().jur_model_destroy(self.h)
+            except TypeError:          # interpreter shutdown: the module globals are gone already
+                pass
             self.h = None
 
     __del__ = close
