@@ -58,6 +58,7 @@ def parse_args(argv):
     ap.add_argument("--rays", type=int, default=0, help="rays of the whole job (default: the workload's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true")
+    ap.add_argument("--no-package-api", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / sharding / gather rehearsal on the CPU (gloo): no library, no GPU, the forward "
                          "model replaced by a checksum of each ray's geometry; the line says dry_run")
@@ -460,6 +461,8 @@ def main(argv):
             out["roofline"]["whole_path_bytes_per_ray"] = ab["total"] / ab["rays"]
             if world == 1 and not args.no_host_inclusive and hasattr(model, "host_buffers"):
                 out["host_inclusive"] = host_inclusive(model, case, args.steps, out["ms_per_step"])
+            if world == 1 and not args.no_package_api:
+                out["package_api"] = package_api(model, case)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
@@ -487,6 +490,20 @@ def host_inclusive(model, case, steps, device_ms):
                      "overhead_vs_device_resident": 1e3 * dt / device_ms - 1.0}
         bufs.close()
     return {"unit": "rays/s", "entry": "jur_formod_host (host arrays in, host arrays out)", **res}
+
+
+def package_api(model, case, nr=1088, calls=40):
+    """the same rays in packages of <= NR = 1088 through the host entry the drop-in formod() uses
+    (one fused kernel per package), one caller thread.  Beside `value`, never `value`."""
+    n = min(nr, len(case.geom))
+    model.formod_host(case.geom[:n])                    # lane warm-up: pinned image of the package
+    t0 = time.perf_counter()
+    for i in range(calls):
+        lo = (i * n) % max(1, len(case.geom) - n)
+        model.formod_host(case.geom[lo:lo + n])
+    dt = (time.perf_counter() - t0) / calls
+    return {"rays_per_call": n, "ms_per_call": 1e3 * dt, "value": n / dt, "unit": "rays/s", "callers": 1,
+            "note": "16 concurrent callers: profiles/r02_lanes_dropin_throughput.json"}
 
 
 if __name__ == "__main__":

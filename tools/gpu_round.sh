@@ -29,7 +29,7 @@ for w in $WHAT; do
            PMC_SHORT=1 step pmc_nadir 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_pmc_nadir --workload nadir_1e5 --steps 1 --warmup 0
            step pmc_nadir_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_nadir nadir_1e5 100000 gpurun_out/${TAG}_pmc_current.json ;;
     lanesmode) for md in "JUR_NO_ZERO_COPY=1" "GPU_MAX_HW_QUEUES=8" "JUR_PENCIL_RAYS=0"; do echo "$md"; EXTRA_ENV="env $md" CALLS=16 bash tools/run_lanes_bench.sh 2>&1 | grep threads; done > $OUTDIR/${TAG}_lanesmode.log 2>&1; cat $OUTDIR/${TAG}_lanesmode.log ;;
-    torchrun1) TAIL=1 step bench_torchrun1 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --no-cpu-baseline --no-host-inclusive ;;
+    torchrun1) TAIL=1 step bench_torchrun1 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --no-cpu-baseline --no-host-inclusive --no-package-api ;;
     wide) TAIL=1 JUR_ND=2378 JUR_NG=3 JUR_SUFFIX=_nd2378 step wide 900 python3 tools/bench_wide.py 4096 ;;
     widestats) cd /tmp; export TMPDIR=/tmp
            JUR_ND=2378 JUR_NG=3 JUR_SUFFIX=_nd2378 step wide_stats 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUTDIR/${TAG}_wide_stats -- python3 $GRAFT_REPO_ROOT/tools/bench_wide.py 4096
@@ -40,7 +40,7 @@ for w in $WHAT; do
            cd $GRAFT_REPO_ROOT
            step wide_pmc_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_wide_pmc wide_2378ch_nadir_4096 4096 gpurun_out/${TAG}_wide_pmc_summary.json ;;
     nadirstats) cd /tmp; export TMPDIR=/tmp
-           step nadir_stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUTDIR/${TAG}_nadir_stats -- python3 $GRAFT_REPO_ROOT/bench.py --workload nadir_1e5 --steps 20 --no-cpu-baseline --no-host-inclusive
+           step nadir_stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUTDIR/${TAG}_nadir_stats -- python3 $GRAFT_REPO_ROOT/bench.py --workload nadir_1e5 --steps 20 --no-cpu-baseline --no-host-inclusive --no-package-api
            cd $GRAFT_REPO_ROOT
            PMC_SHORT=1 step nadir_pmc 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_nadir_pmc --workload nadir_1e5 --steps 1 --warmup 0
            step nadir_pmc_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_nadir_pmc nadir_1e5 100000 gpurun_out/${TAG}_nadir_pmc_summary.json ;;
@@ -68,7 +68,7 @@ PY
            ( cd $D && echo "batched" && JUR_PENCIL_RAYS=0 JUR_LANES=16 $D/lanes_bench 16 16 | tail -1 ) > gpurun_out/${TAG}_lanes_hwq.log 2>&1
            cat gpurun_out/${TAG}_lanes_hwq.log ;;
     stats) cd /tmp; export TMPDIR=/tmp
-           step kernel_stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --no-cpu-baseline --no-host-inclusive
+           step kernel_stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --no-cpu-baseline --no-host-inclusive --no-package-api
            cd $GRAFT_REPO_ROOT ;;
   esac
 done
