@@ -69,7 +69,7 @@ struct jur_model {
   double h_atm_hydz;
   hipStream_t stream;
   hipStream_t stream2;          /* copies that run beside the kernels of `stream` */
-  hipEvent_t ev_mask, ev_trace, ev_side;
+  hipEvent_t ev_mask, ev_trace;
   int host_call;                /* 1 while jur_formod_host drives jur_formod_device: record / wait for the events above */
   void *last_stream;            /* stream of the last jur_formod_device call (see jur_model_set_atm) */
   int have_last_stream;
@@ -118,8 +118,7 @@ static int create_streams(jur_model_t *m) {
       hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_mask, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&m->ev_trace, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&m->ev_trace, hipEventDisableTiming) != hipSuccess) {
     jur_set_error("cannot create the model's streams and events");
     return JUR_EHIP;
   }
@@ -261,7 +260,6 @@ void jur_model_destroy(jur_model_t *m) {
   if (m->stream2) (void)hipStreamDestroy(m->stream2);
   if (m->ev_mask) (void)hipEventDestroy(m->ev_mask);
   if (m->ev_trace) (void)hipEventDestroy(m->ev_trace);
-  if (m->ev_side) (void)hipEventDestroy(m->ev_side);
   if (m->evpool) {
     for (int i = 0; i < 2 * JUR_MAX_TIMED; i++) (void)hipEventDestroy(m->evpool[i]);
     free(m->evpool);
@@ -1171,7 +1169,7 @@ static jur_model_t *clone_lane(jur_model_t const *m) {
   c->d_order = NULL; c->d_sort_tmp = NULL; c->order_cap = 0; c->sort_tmp_bytes = 0;
   c->d_io = NULL; c->d_io_np = NULL; c->io_cap = 0;
   c->h_io = NULL; c->h_io_cap = 0; c->h_pkg = NULL; c->h_atm = NULL; c->h_atm_n = 0; c->h_atm_cap = 0; c->h_status = NULL;
-  c->stream = NULL; c->stream2 = NULL; c->ev_mask = NULL; c->ev_trace = NULL; c->ev_side = NULL;
+  c->stream = NULL; c->stream2 = NULL; c->ev_mask = NULL; c->ev_trace = NULL;
   c->host_call = 0; c->have_last_stream = 0; c->last_stream = NULL;
   c->timing = 0; c->evpool = NULL; c->evkind = NULL; c->ntimed = 0;
   if (hipSetDevice(c->device) != hipSuccess || create_streams(c) != JUR_OK ||
