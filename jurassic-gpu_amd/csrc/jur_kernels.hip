@@ -993,10 +993,22 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   int const np = c.np[r];
   double tau_path = 1.0;
   unsigned br = 0, ia = 0, ib = 0;
+#ifndef JUR_EGA_PREFETCH
+#define JUR_EGA_PREFETCH 0
+#endif
+#if JUR_EGA_PREFETCH
+  double p_next = (np > 0) ? ldg<double>(los_p, r) : 0., t_next = (np > 0) ? ldg<double>(los_t, r) : 0.;
+#endif
   for (int ip = 0; ip < np; ++ip) {
     // (requesting the next segment's p, T, u a segment ahead costs 6 VGPRs = one wave per SIMD: 62.6 vs 60.9 ms)
     size_t const o = (size_t)ip * R;
+#if JUR_EGA_PREFETCH
+    // experiment: p and T (needed first, for the bracket tests) one segment ahead -- 4 VGPRs, still 72
+    double const p = p_next, t = t_next, u = ldg<double>(los_u + o, r);
+    if (ip + 1 < np) { p_next = ldg<double>(los_p + o + R, r); t_next = ldg<double>(los_t + o + R, r); }
+#else
     double const p = ldg<double>(los_p + o, r), t = ldg<double>(los_t + o, r), u = ldg<double>(los_u + o, r);
+#endif
     double eps;
     if constexpr (WARM) eps = ega_eps_warm<LDS, RCPB>(v, pd, D, tau_path, t, u, p, br, ia, ib);
     else eps = ega_eps_exact<LDS>(v, pd, D, tau_path, t, u, p);
