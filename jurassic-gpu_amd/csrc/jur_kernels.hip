@@ -993,22 +993,21 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   int const np = c.np[r];
   double tau_path = 1.0;
   unsigned br = 0, ia = 0, ib = 0;
-#ifndef JUR_EGA_PREFETCH
-#define JUR_EGA_PREFETCH 0
-#endif
-#if JUR_EGA_PREFETCH
-  double p_next = (np > 0) ? ldg<double>(los_p, r) : 0., t_next = (np > 0) ? ldg<double>(los_t, r) : 0.;
-#endif
+  // p and T of a segment -- what the look-up needs first, for its bracket tests -- are requested one segment ahead
+  // (4 VGPRs: 72, still 7 waves per SIMD; -1.5 % kernel time); u, needed only after the first curve search, is not:
+  // with it the kernel drops to 6 waves (62.6 vs 60.9 ms when that was measured).  The warm variants without
+  // reciprocal widths sit at 72 VGPRs already and keep loading at the point of use.
+  constexpr bool AHEAD = RCPB || !WARM;
+  double p_next = 0., t_next = 0.;
+  if (AHEAD && np > 0) { p_next = ldg<double>(los_p, r); t_next = ldg<double>(los_t, r); }
   for (int ip = 0; ip < np; ++ip) {
-    // (requesting the next segment's p, T, u a segment ahead costs 6 VGPRs = one wave per SIMD: 62.6 vs 60.9 ms)
     size_t const o = (size_t)ip * R;
-#if JUR_EGA_PREFETCH
-    // experiment: p and T (needed first, for the bracket tests) one segment ahead -- 4 VGPRs, still 72
-    double const p = p_next, t = t_next, u = ldg<double>(los_u + o, r);
-    if (ip + 1 < np) { p_next = ldg<double>(los_p + o + R, r); t_next = ldg<double>(los_t + o + R, r); }
-#else
-    double const p = ldg<double>(los_p + o, r), t = ldg<double>(los_t + o, r), u = ldg<double>(los_u + o, r);
-#endif
+    double p, t;
+    if constexpr (AHEAD) {
+      p = p_next; t = t_next;
+      if (ip + 1 < np) { p_next = ldg<double>(los_p + o + R, r); t_next = ldg<double>(los_t + o + R, r); }
+    } else { p = ldg<double>(los_p + o, r); t = ldg<double>(los_t + o, r); }
+    double const u = ldg<double>(los_u + o, r);
     double eps;
     if constexpr (WARM) eps = ega_eps_warm<LDS, RCPB>(v, pd, D, tau_path, t, u, p, br, ia, ib);
     else eps = ega_eps_exact<LDS>(v, pd, D, tau_path, t, u, p);
