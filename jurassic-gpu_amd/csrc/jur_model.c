@@ -803,7 +803,14 @@ int jur_formod_host(jur_model_t *m, long nr, double const *const geom[7], double
       if (np_out) HIPCHK(hipMemcpyAsync(h_np, m->d_io_np, sizeof(int) * N, hipMemcpyDeviceToHost, s));
       HIPCHK(hipMemcpyAsync(m->h_status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(hipStreamSynchronize(s));
+    {  /* a package takes about a millisecond: poll instead of a wait that may sleep (in a process whose device is
+        * set to blocking synchronisation -- PyTorch's default -- hipStreamSynchronize adds about 1 ms per call) */
+      hipError_t q;
+      int spins = 0;
+      while ((q = hipStreamQuery(s)) == hipErrorNotReady)
+        if (++spins > 2000) sched_yield();
+      if (q != hipSuccess) { jur_set_error("HIP error %d (%s) while waiting for the package", (int)q, hipGetErrorString(q)); return JUR_EHIP; }
+    }
     status = *m->h_status;
     memcpy(rad, h_rad, sizeof(double) * nrd);
     memcpy(tau, h_tau, sizeof(double) * nrd);
