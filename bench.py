@@ -496,12 +496,16 @@ def package_api(model, case, nr=1088, calls=40):
     """the same rays in packages of <= NR = 1088 through the host entry the drop-in formod() uses
     (one fused kernel per package), one caller thread.  Beside `value`, never `value`."""
     n = min(nr, len(case.geom))
-    model.formod_host(case.geom[:n])                    # lane warm-up: pinned image of the package
+    bufs = model.host_buffers(n, pinned=False)          # ordinary host arrays, as an obs_t's are; allocated once
+    bufs.set_geometry(case.geom[:n])
+    model.formod_host_buffers(bufs)                     # warm-up: the model's pinned image of a package
     t0 = time.perf_counter()
     for i in range(calls):
         lo = (i * n) % max(1, len(case.geom) - n)
-        model.formod_host(case.geom[lo:lo + n])
+        bufs.set_geometry(case.geom[lo:lo + n])
+        model.formod_host_buffers(bufs)
     dt = (time.perf_counter() - t0) / calls
+    bufs.close()
     return {"rays_per_call": n, "ms_per_call": 1e3 * dt, "value": n / dt, "unit": "rays/s", "callers": 1,
             "note": "16 concurrent callers: profiles/r02_lanes_dropin_throughput.json"}
 
