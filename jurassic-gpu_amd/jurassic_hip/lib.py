@@ -251,9 +251,15 @@ class Model:
 
     def formod_host_buffers(self, b):
         """jur_formod_host on preallocated arrays (b.rad is read for the NaN mask, then overwritten)."""
+        import time
         garr = (dp * 7)(*[_p(b.geom[k]) for k in range(7)])
         tarr = (dp * 3)(*[_p(b.tp[k]) for k in range(3)])
-        _chk(lib().jur_formod_host(self.h, b.nr, garr, _p(b.rad), _p(b.tau), tarr, b.np.ctypes.data_as(C.POINTER(C.c_int))))
+        args = (self.h, b.nr, garr, _p(b.rad), _p(b.tau), tarr, b.np.ctypes.data_as(C.POINTER(C.c_int)))
+        t0 = time.perf_counter()
+        rc = lib().jur_formod_host(*args)
+        dt = time.perf_counter() - t0
+        _chk(rc)
+        return dt                                  # seconds inside the library call
 
     def curtis_godson(self, geom):
         """-> dict(cgp, cgt, cgu (nr, ng, NLOS), np)."""
