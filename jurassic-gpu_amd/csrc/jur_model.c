@@ -141,6 +141,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   if (!m) return JUR_ENOMEM;
   m->device = device;
   m->ctl = (ctl_t *)malloc(sizeof(ctl_t));
+  if (!m->ctl) { free(m); return JUR_ENOMEM; }
   memcpy(m->ctl, ctl, sizeof(ctl_t));
   jur_view_t *v = &m->view;
   v->ng = ctl->ng; v->nd = ctl->nd; v->nw = ctl->nw > 0 ? ctl->nw : 1;
@@ -154,6 +155,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
              + (1 == ctl->ctm_n2) * 2 + (1 == ctl->ctm_o2) * 1;
 
   jur_chan_t *chan = (jur_chan_t *)calloc(ctl->nd, sizeof(jur_chan_t));
+  if (!chan) { jur_model_destroy(m); return JUR_ENOMEM; }
   for (int id = 0; id < ctl->nd; id++)
     if ((rc = jur_chan_setup(&chan[id], ctl->nu[id], ctl->window[id]))) { free(chan); jur_model_destroy(m); return rc; }
   rc = upload(&m->d_chan, chan, sizeof(jur_chan_t) * ctl->nd);
@@ -166,6 +168,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   jur_pair_t *subpair = NULL;
   if (tb->nd != ctl->nd || tb->ng != ctl->ng) {
     subpair = (jur_pair_t *)calloc((size_t)ctl->ng * ctl->nd + 1, sizeof(jur_pair_t));
+    if (!subpair) { jur_model_destroy(m); return JUR_ENOMEM; }
     for (int g = 0; g < ctl->ng; g++)
       for (int d = 0; d < ctl->nd; d++) subpair[(size_t)g * ctl->nd + d] = tb->pair[(size_t)g * tb->nd + d];
     sub.pair = subpair; sub.ng = ctl->ng; sub.nd = ctl->nd;
@@ -208,7 +211,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   if (getenv("JUR_WS_GIB") && atoi(getenv("JUR_WS_GIB")) >= 1) m->ws_budget = (long)atoi(getenv("JUR_WS_GIB")) << 30;
   if ((rc = create_streams(m))) { jur_model_destroy(m); return rc; }
   if ((rc = upload((void **)&m->d_status, NULL, sizeof(int)))) { jur_model_destroy(m); return rc; }
-  HIPCHK(hipMemset(m->d_status, 0, sizeof(int)));
+  if (hipMemset(m->d_status, 0, sizeof(int)) != hipSuccess) { jur_set_error("cannot clear the status word"); jur_model_destroy(m); return JUR_EHIP; }
   *out = m;
   return JUR_OK;
 }
