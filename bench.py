@@ -354,6 +354,8 @@ def main(argv):
         if not dry:
             torch.cuda.synchronize()
 
+    if use_dist:    # RCCL sets up a peer-to-root connection on first use: do that before any step, also with --warmup 0
+        shard.gather_rows(torch.zeros((1, nd), dtype=torch.float64, device=dev), [1] * world, dst=0)
     for _ in range(args.warmup):
         full_step()
     fence()
