@@ -638,6 +638,71 @@ __device__ __forceinline__ void seek_curve(void const *__restrict__ ue, unsigned
   }
 }
 
+// fp32 -> fp64 as an instruction the compiler may neither repeat nor re-create at a later use: left to itself it
+// keeps the four floats of a bracket and converts them again wherever a double is wanted (48 conversions per
+// look-up, 12 % of its vector instructions); held as doubles from the test that needs them first, it is 28.
+__device__ __forceinline__ double cvt_keep(float f) {
+  double d;
+  asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d) : "v"(f));
+  return d;
+}
+template <bool ON_EPS>
+__device__ __forceinline__ double kkey(Ue const &e) { return cvt_keep(ON_EPS ? e.eps : e.u); }
+
+// seek_curve that works on, and hands back, the keys of its bracket as doubles: ka = key(e[i]), kb = key(e[i+1]) --
+// formed here unless the caller HAS them already (get_eps's search starts on the bracket whose column keys get_u's
+// interpolation has just converted).  Same probes, same bracket as seek_curve.  (The two far-move branches each end in
+// their own reload: with a shared tail the register allocator needs 91 VGPRs for jur_ega_kernel instead of 71 --
+// tests/test_abi_cpu.py watches that number.)
+template <bool ON_EPS, bool HAVE>
+__device__ __forceinline__ void seek_curve_keys(void const *__restrict__ ue, unsigned e0, int n, double x, int &i, Ue &a, Ue &b,
+                                                double &ka, double &kb) {
+  if (!HAVE) { ka = kkey<ON_EPS>(a); kb = kkey<ON_EPS>(b); }
+  bool const up = x >= kb, down = x < ka;
+  if (!(up | down)) return;
+  if (up) {
+    if (i >= n - 2) return;
+    Ue const c = ld_ue(ue, e0 + i + 2);
+    double const kc = kkey<ON_EPS>(c);
+    if (i + 2 >= n - 1 || kc > x) { ++i; a = b; b = c; ka = kb; kb = kc; return; }
+    int lo = i + 2, hi, step = 2;
+    for (;;) {
+      hi = lo + step;
+      if (hi >= n - 1) { hi = n - 1; break; }
+      if (ukey<ON_EPS>(ld_ue(ue, e0 + hi)) > x) break;
+      lo = hi;
+      step <<= 1;
+    }
+    while (hi > lo + 1) {
+      int const mid = (lo + hi) >> 1;
+      if (ukey<ON_EPS>(ld_ue(ue, e0 + mid)) > x) hi = mid; else lo = mid;
+    }
+    i = lo;
+    ld_pair(ue, e0 + i, a, b);
+    ka = kkey<ON_EPS>(a); kb = kkey<ON_EPS>(b);
+  } else {
+    if (i <= 0) return;
+    Ue const c = ld_ue(ue, e0 + i - 1);
+    double const kc = kkey<ON_EPS>(c);
+    if (i - 1 <= 0 || kc <= x) { --i; b = a; a = c; kb = ka; ka = kc; return; }
+    int hi = i - 1, lo, step = 2;
+    for (;;) {
+      lo = hi - step;
+      if (lo <= 0) { lo = 0; break; }
+      if (ukey<ON_EPS>(ld_ue(ue, e0 + lo)) <= x) break;
+      hi = lo;
+      step <<= 1;
+    }
+    while (hi > lo + 1) {
+      int const mid = (lo + hi) >> 1;
+      if (ukey<ON_EPS>(ld_ue(ue, e0 + mid)) > x) hi = mid; else lo = mid;
+    }
+    i = lo;
+    ld_pair(ue, e0 + i, a, b);
+    ka = kkey<ON_EPS>(a); kb = kkey<ON_EPS>(b);
+  }
+}
+
 // Table descriptors of ONE (gas, channel) pair as the look-up sees them: read from global memory, or
 // from a copy the workgroup has staged in LDS (every lane of the workgroup works on the same pair; LDS
 // reads are counted by lgkmcnt and stay out of the queue of the curve gathers).
@@ -755,7 +820,6 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
   // RCPB clamps with min/max, which would turn a NaN into 0: a NaN among the inputs (the tables hold none) is
   // answered here with what the comparisons of c01 would have handed through
   if (RCPB && (tau != tau || t != t || u != u || p != p)) return __builtin_nan("");
-  auto CL = [](double x) { return RCPB ? c01_num(x) : c01(x); };
   double const eps = 1 - tau;
   double eps_p0 = 0, eps_p1 = 0;
 #pragma unroll 1
@@ -776,18 +840,30 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
     // emissivity at that u plus the segment's column -- the column only grows, so the second search
     // starts where the first ended
     double x[2], ec[2];
+    if constexpr (RCPB) {  // the keys of each bracket as doubles from the search that tests them to the interpolation
+      double ka[2], kb[2];
 #pragma unroll
-    for (int k = 0; k < 2; k++) seek_curve<true>(ueb, e0[k], n[k], eps, i[k], a[k], b[k]);
+      for (int k = 0; k < 2; k++) seek_curve_keys<true, false>(ueb, e0[k], n[k], eps, i[k], a[k], b[k], ka[k], kb[k]);
 #pragma unroll
-    for (int k = 0; k < 2; k++)
-      x[k] = (RCPB ? lip_finite((double)a[k].eps, (double)a[k].u, (double)b[k].eps, (double)b[k].u, eps)
-                   : lip((double)a[k].eps, (double)a[k].u, (double)b[k].eps, (double)b[k].u, eps)) + u;
+      for (int k = 0; k < 2; k++) {
+        double const ya = kkey<false>(a[k]), yb = kkey<false>(b[k]);    // ... which serve get_eps's search as its keys
+        x[k] = lip_finite(ka[k], ya, kb[k], yb, eps) + u;
+        ka[k] = ya; kb[k] = yb;
+      }
 #pragma unroll
-    for (int k = 0; k < 2; k++) seek_curve<false>(ueb, e0[k], n[k], x[k], i[k], a[k], b[k]);
+      for (int k = 0; k < 2; k++) seek_curve_keys<false, true>(ueb, e0[k], n[k], x[k], i[k], a[k], b[k], ka[k], kb[k]);
 #pragma unroll
-    for (int k = 0; k < 2; k++)
-      ec[k] = CL(RCPB ? lip_finite((double)a[k].u, (double)a[k].eps, (double)b[k].u, (double)b[k].eps, x[k])
-                       : lip((double)a[k].u, (double)a[k].eps, (double)b[k].u, (double)b[k].eps, x[k]));
+      for (int k = 0; k < 2; k++) ec[k] = c01_num(lip_finite(ka[k], (double)a[k].eps, kb[k], (double)b[k].eps, x[k]));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; k++) seek_curve<true>(ueb, e0[k], n[k], eps, i[k], a[k], b[k]);
+#pragma unroll
+      for (int k = 0; k < 2; k++) x[k] = lip((double)a[k].eps, (double)a[k].u, (double)b[k].eps, (double)b[k].u, eps) + u;
+#pragma unroll
+      for (int k = 0; k < 2; k++) seek_curve<false>(ueb, e0[k], n[k], x[k], i[k], a[k], b[k]);
+#pragma unroll
+      for (int k = 0; k < 2; k++) ec[k] = c01(lip((double)a[k].u, (double)a[k].eps, (double)b[k].u, (double)b[k].eps, x[k]));
+    }
     unsigned const last = (unsigned)i[0] | ((unsigned)i[1] << 16);
     if (h) ib = last; else ia = last;
     double e;
@@ -795,7 +871,13 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
     else e = c01(lip(ca.t, ec[0], cb.t, ec[1], t));
     if (h) eps_p1 = e; else eps_p0 = e;
   }
-  if constexpr (RCPB) return div_finite(1. - c01_num(lip_rcp(l0.p, eps_p0, l1.p, eps_p1, p, D.rp(ipr))), tau);
+  if constexpr (RCPB) {
+    // the two level pressures are read from LDS again rather than kept through both levels: 4 VGPRs, which is what
+    // keeps the kernel at 7 waves per SIMD with the keys held as doubles
+    int q = ipr;
+    asm volatile("" : "+v"(q));
+    return div_finite(1. - c01_num(lip_rcp(D.lvl(q).p, eps_p0, D.lvl(q + 1).p, eps_p1, p, D.rp(q))), tau);
+  }
   return (1. - c01(lip(l0.p, eps_p0, l1.p, eps_p1, p))) / tau;
 }
 
