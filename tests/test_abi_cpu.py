@@ -274,3 +274,30 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert "oracle" not in txt.lower(), f"{f} mentions the oracle"
+
+
+def test_kernel_register_budgets(tmp_path):
+    """The batched kernels' occupancy is part of their measured speed and hangs on a few registers (DESIGN 4.3, 8 vii):
+    jur_ega_kernel must stay within 72 VGPRs (7 wavefronts per SIMD), jur_combine_kernel within 80 (6), the tracer
+    within 128 (4); jur_ega_kernel uses no scratch memory at all, the other two no more than the few doubles they keep
+    there today (outside their inner loops)."""
+    import subprocess
+    csrc = os.path.join(common.ROOT, "jurassic-gpu_amd", "csrc")
+    asm = tmp_path / "k.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-ffp-contract=off", "-std=c++17",
+                           "-I" + os.path.join(common.ROOT, "include"), "-I" + csrc, "-DJUR_ND=100", "-DJUR_NG=30", "-S",
+                           "--cuda-device-only", "-o", str(asm), os.path.join(csrc, "jur_kernels.hip")],
+                          stderr=subprocess.DEVNULL)
+    text = asm.read_text()
+    meta = text[text.index("amdhsa.kernels:"):]
+    seen = {}
+    for block in meta.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        seen[name] = (int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)),
+                      int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)))
+    budget = {"jur_ega_kernelILb1ELb1ELb1E": (72, 0), "jur_combine_kernel": (80, 40), "jur_trace_kernel": (128, 32)}
+    for key, (limit, scratch_limit) in budget.items():
+        hits = {n: v for n, v in seen.items() if key in n and "kat" not in n}
+        assert len(hits) == 1, (key, list(seen))
+        (vgprs, scratch), = hits.values()
+        assert vgprs <= limit and scratch <= scratch_limit, (key, vgprs, scratch)
