@@ -93,6 +93,7 @@ int jurk_prepare_atm(jur_view_t const *v, double *d_pslope, void *stream);   /* 
 int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, void *stream);
+void jurk_tune_combine(int group, int sync, long min_lanes);
 /* Curtis-Godson columns of the traced chunk: outputs [ray][gas][JUR_NLOS], indexed by ray id */
 int jurk_launch_cg(jur_view_t const *v, jur_chunk_t const *c, double *cgp, double *cgt, double *cgu, void *stream);
 /* order rays by their geometric tangent altitude: fills order[nr]; `tmp` is a

@@ -13,6 +13,8 @@
 //                         (jr_common.h:315-390), product over gases, Planck source (:220-224),
 //                         radiance update (:293-300); surface term, brightness temperature and
 //                         the NaN mask in the epilogue (CPUdrivers.c:5-24, jr_common.h:193-210).
+//   jur_combine_group_kernel  the same with up to four channels of a ray block as the wavefronts of one
+//                         workgroup (what runs when there is more than one channel).
 //   Two table-search strategies in jur_ega_kernel: WARM (tables whose axes and curves are sorted: every
 //   bracket is unique, so the search resumes from the bracket the previous segment ended in -- the
 //   accumulated transmittance only falls, the column only grows) and EXACT (the reference's bisections
@@ -1153,6 +1155,78 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
   c.tau[oidx] = tau;
 }
 
+// jur_combine_group_kernel: the same lane program with the channels of a ray block as wavefronts of ONE workgroup --
+// wave w works on channel cg * CG + w % CG for the 64 rays of sub-block w / CG (CG = min(nd, 4) channels per group,
+// 8 / CG sub-blocks, 6 or 8 waves) -- and a barrier every SYNC segments that keeps the waves within reach of each
+// other: the LOS rows of a segment, which every channel reads, are then found in L2 by all but the first reader
+// (FETCH_SIZE of the kernel -29 %).  The kernel waits on its dependent chains more than on HBM, so this is worth
+// 4 % of its time, not 29 (17.3 against 18.1 ms per 1e6 limb rays); one channel per workgroup remains for nd = 1.
+// The wave index is made uniform (readfirstlane) so that the channel constants stay in scalar registers.
+__global__ __launch_bounds__(512, 6) void jur_combine_group_kernel(jur_view_t v, jur_chunk_t c, int nsb, int CG, int SYNC) {   // SYNC: mask, see the loop
+  int const nd = v.nd, ng = v.ng;
+  int const ncg = (nd + CG - 1) / CG, SUB = (int)(blockDim.x >> 6) / CG;
+  int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
+  int const sb = (sq / ncg) * 8 + xcd, cg = sq - (sq / ncg) * ncg;   // ray super-block, channel group: uniform
+  if (sb >= nsb) return;
+  int const w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);   // uniform: channel constants stay in SGPRs
+  int const cw = w % CG, sub = w / CG;
+  int const d = cg * CG + cw;
+  bool const live_wave = d < nd;
+  double *const sr = reinterpret_cast<double *>(jur_lds) + (size_t)cw * TBLNS;
+  int *const npmax_sh = reinterpret_cast<int *>(reinterpret_cast<double *>(jur_lds) + (size_t)CG * TBLNS);
+  if (threadIdx.x == 0) *npmax_sh = 0;
+  for (int k = 0; k < CG; k++) {
+    if (cg * CG + k >= nd) break;
+    double const *const gsr = v.sr + (size_t)(cg * CG + k) * TBLNS;
+    double *const dst = reinterpret_cast<double *>(jur_lds) + (size_t)k * TBLNS;
+    for (int i = threadIdx.x; i < TBLNS; i += blockDim.x) dst[i] = gsr[i];
+  }
+  __syncthreads();
+  int const r = (sb * SUB + sub) * 64 + lane;
+  bool const live = live_wave && r < c.n;
+  int const np = live ? c.np[r] : 0;
+  atomicMax(npmax_sh, np);
+  __syncthreads();
+  int const npmax = *npmax_sh;
+  long const ray = live ? (c.order ? (long)c.order[r] : c.first + r) : 0;
+  size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
+  size_t const Re = (size_t)c.stride_eps, fe = (size_t)NLOS * Re;
+  double const *const los = c.los;
+  int const dd = live_wave ? d : 0;
+  double const *const epsb = c.eps + (size_t)dd * ng * fe;
+  jur_chan_t const ch = v.chan[dd];
+  int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
+  bool const do_co2 = (v.fourbit & 8) && ch.co2_on, do_h2o = (v.fourbit & 4) && ch.h2o_on,
+             do_n2 = (v.fourbit & 2) && ch.n2_on, do_o2 = (v.fourbit & 1) && ch.o2_on;
+  size_t const oidx = (size_t)ray * nd + dd;
+  bool const masked = live && !isfinite(c.rad[oidx]);
+  double rad = 0.0, tau = 1.0;
+  unsigned has_table = 0;
+  for (int g = 0; g < ng && g < 32; g++) has_table |= (v.pair[g * nd + dd].a >= 2 ? 1u : 0u) << g;
+  for (int ip = 0; ip < npmax; ++ip) {
+    if (ip < np) {
+      size_t const o = (size_t)ip * R;
+      auto L = [&](int field) { return ldg<double>(los + (size_t)field * fs + o, r); };
+      double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
+      double beta_ds = L(f_k) * ds;
+      if (do_co2) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
+      if (do_h2o) beta_ds += ctm_h2o(ch, p, t, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
+      if (do_n2) beta_ds += ctm_n2(ch, p, t) * ds;
+      if (do_o2) beta_ds += ctm_o2(ch, p, t) * ds;
+      double tau_gas = 1.0;
+      for (int g = 0; g < ng; g++)
+        if ((has_table >> g) & 1u) tau_gas *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
+      new_obs_step(tau_gas, beta_ds, planck_src(sr, t), rad, tau);
+    }
+    if ((ip & SYNC) == SYNC) __syncthreads();      // SYNC = 2^k - 1 (0: a barrier after every segment; -1 never matches: none)
+  }
+  if (!live) return;
+  ray_epilogue(sr, ch.nu, c.tsurf[r], v.write_bbt, rad, tau);
+  if (masked) rad = __builtin_nan("");
+  c.rad[oidx] = rad;
+  c.tau[oidx] = tau;
+}
+
 // ---------------------------------------------------------------------------------------
 // jur_pencil_kernel: the whole path of a ray pencil inside ONE workgroup -- for calls of the size the
 // reference's callers make (packages of <= NR = 1088 rays, formod.c:100, kernel() jurassic.c:844), which cannot
@@ -1764,11 +1838,39 @@ extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *
   return (int)hipGetLastError();
 }
 
+// how jur_combine runs: channels per workgroup (0: always one channel per workgroup), segments between barriers,
+// smallest launch (rays x channels) that takes the grouped kernel
+static int g_combine_group = -1, g_combine_sync = 8;
+static long g_combine_min_lanes = 1000000L;
+extern "C" void jurk_tune_combine(int group, int sync, long min_lanes) {
+  g_combine_group = group < 0 ? 4 : (group > 6 ? 6 : group);   // 6 source-function tables fill the 64 KB of LDS a launch may ask for
+  g_combine_sync = sync;
+  g_combine_min_lanes = min_lanes;
+}
+
 extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
   if (c->n <= 0) return 0;
   int const block = 256;
   int const nrb = (c->n + block - 1) / block;
   unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * v->nd);
+  if (g_combine_group < 0) {                       // first launch: the environment may override the defaults (A/B switch)
+    g_combine_group = getenv("JUR_COMBINE_GROUP") ? atoi(getenv("JUR_COMBINE_GROUP")) : 4;
+    if (g_combine_group > 6) g_combine_group = 6;
+    if (getenv("JUR_COMBINE_SYNC")) g_combine_sync = atoi(getenv("JUR_COMBINE_SYNC"));
+  }
+  int const group = g_combine_group, sync = g_combine_sync;
+  // grouped only when the launch fills the chip several times over: below that a call is as long as its longest
+  // chain, and barriers between wavefronts lengthen it (nadir_1e5, 3e5 lanes: 0.66 against 0.37 ms)
+  if (group > 0 && v->nd > 1 && (long)c->n * v->nd >= g_combine_min_lanes) {
+    int const CG = v->nd < group ? v->nd : group, SUB = 8 / CG, W = CG * SUB;
+    int const nsb = (c->n + SUB * 64 - 1) / (SUB * 64), ncg = (v->nd + CG - 1) / CG;
+    unsigned const g2 = (unsigned)(((nsb + 7) / 8) * 8 * ncg);
+    int mask = -1;                                 // barrier every 2^k segments, k from JUR_COMBINE_SYNC (<= 0: none)
+    if (sync > 0) { mask = 1; while (mask * 2 <= sync) mask *= 2; mask -= 1; }
+    hipLaunchKernelGGL(jur_combine_group_kernel, dim3(g2), dim3(64 * W), sizeof(double) * JUR_TBLNS * CG + 16, (hipStream_t)stream,
+                       *v, *c, nsb, CG, mask);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(jur_combine_kernel, dim3(grid), dim3(block), sizeof(double) * JUR_TBLNS, (hipStream_t)stream, *v, *c,
                      nrb);
   return (int)hipGetLastError();

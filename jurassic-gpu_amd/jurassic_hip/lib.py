@@ -71,6 +71,8 @@ def lib():
         L.jur_model_last_kernel_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
         L.jur_model_last_pencil_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
         L.jur_model_set_pencil.argtypes = [C.c_void_p, C.c_long, C.c_int]
+        L.jur_tune_combine.argtypes = [C.c_int, C.c_int, C.c_long]
+        L.jur_tune_combine.restype = None
         L.jur_state_size.restype = C.c_size_t
         L.jur_state_size.argtypes = [C.c_void_p, C.c_void_p]
         L.jur_measurement_size.restype = C.c_size_t
@@ -359,3 +361,8 @@ def fov_apply(time, vpz, rad, tau, dz, w):
 
 def formod_pencil(ctl, atm, obs, ir):
     lib().formod_pencil(C.byref(ctl), C.byref(atm), C.byref(obs), ir)
+
+
+def tune_combine(channels_per_group=4, sync_segments=8, min_lanes=1_000_000):
+    """Process-wide arrangement of the radiance-update kernel of the batched path (jur_tune_combine)."""
+    lib().jur_tune_combine(channels_per_group, sync_segments, min_lanes)

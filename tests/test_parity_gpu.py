@@ -904,3 +904,36 @@ def test_fov_convolution_on_device_arrays(hip, oracle):
     with pytest.raises(hip.JurassicError, match="Cannot apply FOV"):
         model.fov_apply_device(3, lone.data_ptr(), d_geom[4].data_ptr(), d_rad.data_ptr(), d_tau.data_ptr(), dz, w, stream)
     model.close()
+
+
+@pytest.mark.parametrize("nchan", [2, 3, 4, 5, 7])
+def test_grouped_radiance_update_kernel_equals_one_channel_per_workgroup(hip, nchan):
+    """jur_combine_group_kernel (up to four channels of a ray block as the wavefronts of one workgroup, barriers between
+    them; what large launches take) against jur_combine_kernel: the same lane program, so every output must agree BIT
+    FOR BIT -- for every group shape (2, 3, 4 channels; a ragged last group for 5 and 7), ragged ray counts, rays
+    that miss the atmosphere, masked inputs and every barrier interval."""
+    nu = list(np.round(np.linspace(700.0, 2400.0, nchan), 4))
+    g = synth.limb_geometry(1500 + 37 * nchan, seed=nchan, nprofiles=3)
+    extra = np.array([[0, 780.0, 0, 0, 95.0, 0, 20.0], [1, 30.0, 0, 0, 5.0, 0, 3.0]])      # outside; observer inside
+    geom = np.vstack([g[:700], extra, g[700:], synth.nadir_geometry(90, seed=2, nprofiles=3)])
+    case = common.Case(["CO2", "H2O", "O3"], nu, os.path.join(common.GOLD, "limb", "atm.tab"), geom, nprofiles=3)
+    rad_in = np.zeros((len(geom), nchan))
+    rad_in[5, 0] = np.nan
+    rad_in[701, nchan - 1] = np.inf
+    m = hip.Model(case.ctl, case.lib_tables())
+    m.set_atm(case.atm)
+    m.set_pencil(0)                                  # the batched kernels
+    try:
+        hip.tune_combine(0, 8, 0)
+        ref = m.formod_host(case.geom, rad_in=rad_in)
+        assert np.isnan(ref["rad"][5, 0]) and np.isnan(ref["rad"][701, nchan - 1]) and ref["np"][700] == 0
+        for group, sync in ((4, 8), (4, 1), (4, 0), (2, 2), (8, 4)):
+            hip.tune_combine(group, sync, 0)
+            out = m.formod_host(case.geom, rad_in=rad_in)
+            for k in ("rad", "tau", "tp", "np"):
+                x, y = np.asarray(out[k]), np.asarray(ref[k])
+                assert np.array_equal(np.isnan(x), np.isnan(y)) if x.dtype.kind == "f" else True
+                assert np.array_equal(np.nan_to_num(x, nan=-1.0).view(np.uint8), np.nan_to_num(y, nan=-1.0).view(np.uint8)), (k, group, sync)
+    finally:
+        hip.tune_combine(4, 8, 1_000_000)
+        m.close()
