@@ -26,7 +26,7 @@ for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), rec
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         short = ("trace" if "jur_trace_kernel" in k else "ega" if "jur_ega_kernel" in k else
-                 "combine" if "jur_combine_kernel" in k else "pencil" if "jur_pencil_kernel" in k else None)
+                 "combine" if "jur_combine" in k else "pencil" if "jur_pencil_kernel" in k else None)
         if short is None:
             continue
         agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
