@@ -1857,6 +1857,7 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
     g_combine_group = getenv("JUR_COMBINE_GROUP") ? atoi(getenv("JUR_COMBINE_GROUP")) : 4;
     if (g_combine_group > 6) g_combine_group = 6;
     if (getenv("JUR_COMBINE_SYNC")) g_combine_sync = atoi(getenv("JUR_COMBINE_SYNC"));
+    if (getenv("JUR_COMBINE_MIN_LANES")) g_combine_min_lanes = atol(getenv("JUR_COMBINE_MIN_LANES"));
   }
   int const group = g_combine_group, sync = g_combine_sync;
   // grouped only when the launch fills the chip several times over: below that a call is as long as its longest
