@@ -44,11 +44,15 @@ def assert_parity(out, ref, rtol=RTOL):
     fin = np.isfinite(ref["rad"])
     assert np.array_equal(fin, np.isfinite(out["rad"]))
     assert common.rel_err(out["rad"][fin], ref["rad"][fin]).max() < rtol
-    # transmittances of opaque paths (tau << 1e-6) come out of (1 - eps)/tau with eps -> 1 and are
-    # ill-conditioned in the algorithm itself: relative 1e-9 or absolute 1e-13 (tau lives in [0,1]), whichever is larger
+    # transmittances of optically thick paths come out of (1 - eps)/tau with eps -> 1 and are ill-conditioned in the
+    # algorithm itself: every look-up leaves ~1e-15 of ABSOLUTE rounding in eps, i.e. ~1e-15 / tau relative in the path
+    # transmittance, over some hundred segments.  Relative 1e-9 or absolute 5e-12 (tau lives in [0, 1]), whichever is
+    # larger.  (Until 6 000 random configurations the floor was 1e-13; seeds 31088 and 40345 of tools/fuzz_parity.py
+    # reach 3.5e-13 and 1.2e-12 at tau ~ 1e-4 -- with every variant of the kernels, old and new, to the same bits:
+    # the last bits in which device and host libm differ (ray tracer, continua), amplified; radiances agree to 6e-12.)
     terr = np.abs(out["tau"] - ref["tau"])
     k = np.unravel_index(np.argmax(terr - rtol * np.abs(ref["tau"])), terr.shape)
-    assert np.all(terr <= rtol * np.abs(ref["tau"]) + 1e-13), (k, out["tau"][k], ref["tau"][k])
+    assert np.all(terr <= rtol * np.abs(ref["tau"]) + 5e-12), (k, out["tau"][k], ref["tau"][k])
     assert np.abs(out["tp"][:, 0] - ref["tp"][:, 0]).max() < 1e-9      # km
     assert np.abs(out["tp"][:, 1:] - ref["tp"][:, 1:]).max() < 1e-10   # deg
 
