@@ -187,7 +187,9 @@ int  jur_model_set_pencil(jur_model_t *m, long max_rays, int rays_per_group);
 /* Process-wide tuning of the radiance-update kernel of the batched path: up to `channels_per_group` (0 .. 6, default
  * 4; 0 = one channel per workgroup always) channels of a ray block share a workgroup, with a barrier every
  * `sync_segments` segments (default 8; <= 0 none), for launches of at least `min_lanes` rays x channels (default
- * 1 000 000).  Results do not depend on it (tests/test_parity_gpu.py compares the arrangements bit for bit). */
+ * 1 000 000).  Without a call (or after one with channels_per_group < 0) the library groups by four, and only when
+ * the channel count is a multiple of four: other group shapes were measured slower than one channel per workgroup.
+ * Results do not depend on it (tests/test_parity_gpu.py compares the arrangements bit for bit). */
 void jur_tune_combine(int channels_per_group, int sync_segments, long min_lanes);
 
 /* Summed duration in ms and launch count of each kernel since the last query,

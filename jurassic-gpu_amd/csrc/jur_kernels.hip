@@ -1840,9 +1840,10 @@ extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *
 
 // how jur_combine runs: channels per workgroup (0: always one channel per workgroup), segments between barriers,
 // smallest launch (rays x channels) that takes the grouped kernel
-static int g_combine_group = -1, g_combine_sync = 8;
+static int g_combine_group = -1, g_combine_sync = 8, g_combine_forced = 0;
 static long g_combine_min_lanes = 1000000L;
 extern "C" void jurk_tune_combine(int group, int sync, long min_lanes) {
+  g_combine_forced = group >= 0;                 // < 0: back to the defaults and the default rule
   g_combine_group = group < 0 ? 4 : (group > 6 ? 6 : group);   // 6 source-function tables fill the 64 KB of LDS a launch may ask for
   g_combine_sync = sync;
   g_combine_min_lanes = min_lanes;
@@ -1855,14 +1856,19 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
   unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * v->nd);
   if (g_combine_group < 0) {                       // first launch: the environment may override the defaults (A/B switch)
     g_combine_group = getenv("JUR_COMBINE_GROUP") ? atoi(getenv("JUR_COMBINE_GROUP")) : 4;
+    g_combine_forced = getenv("JUR_COMBINE_GROUP") != NULL;
     if (g_combine_group > 6) g_combine_group = 6;
     if (getenv("JUR_COMBINE_SYNC")) g_combine_sync = atoi(getenv("JUR_COMBINE_SYNC"));
     if (getenv("JUR_COMBINE_MIN_LANES")) g_combine_min_lanes = atol(getenv("JUR_COMBINE_MIN_LANES"));
   }
   int const group = g_combine_group, sync = g_combine_sync;
-  // grouped only when the launch fills the chip several times over: below that a call is as long as its longest
-  // chain, and barriers between wavefronts lengthen it (nadir_1e5, 3e5 lanes: 0.66 against 0.37 ms)
-  if (group > 0 && v->nd > 1 && (long)c->n * v->nd >= g_combine_min_lanes) {
+  // grouped only when the launch fills the chip several times over -- below that a call is as long as its longest
+  // chain, and barriers between wavefronts lengthen it (nadir_1e5, 3e5 lanes: 0.66 against 0.37 ms) -- and, by
+  // default, only when the channels fall into full groups of four: groups of two or three and ragged last groups were
+  // measured slower than one channel per workgroup (tools/bench_combine_groups.py: 2 channels +7 %, 3 +17 %,
+  // 6 = 4 + 2 +27 %).  A group size set through jur_tune_combine / JUR_COMBINE_GROUP is taken as it is.
+  bool const fits = g_combine_forced || (group == 4 && v->nd % 4 == 0);
+  if (group > 0 && v->nd > 1 && fits && (long)c->n * v->nd >= g_combine_min_lanes) {
     int const CG = v->nd < group ? v->nd : group, SUB = 8 / CG, W = CG * SUB;
     int const nsb = (c->n + SUB * 64 - 1) / (SUB * 64), ncg = (v->nd + CG - 1) / CG;
     unsigned const g2 = (unsigned)(((nsb + 7) / 8) * 8 * ncg);

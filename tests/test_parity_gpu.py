@@ -939,5 +939,5 @@ def test_grouped_radiance_update_kernel_equals_one_channel_per_workgroup(hip, nc
                 assert np.array_equal(np.isnan(x), np.isnan(y)) if x.dtype.kind == "f" else True
                 assert np.array_equal(np.nan_to_num(x, nan=-1.0).view(np.uint8), np.nan_to_num(y, nan=-1.0).view(np.uint8)), (k, group, sync)
     finally:
-        hip.tune_combine(4, 8, 1_000_000)
+        hip.tune_combine(-1, 8, 1_000_000)              # back to the default rule
         m.close()
