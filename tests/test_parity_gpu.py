@@ -938,6 +938,16 @@ def test_grouped_radiance_update_kernel_equals_one_channel_per_workgroup(hip, nc
                 x, y = np.asarray(out[k]), np.asarray(ref[k])
                 assert np.array_equal(np.isnan(x), np.isnan(y)) if x.dtype.kind == "f" else True
                 assert np.array_equal(np.nan_to_num(x, nan=-1.0).view(np.uint8), np.nan_to_num(y, nan=-1.0).view(np.uint8)), (k, group, sync)
+        # several launches per call (chunks of 448 rays, tracing launches of two chunks) and unsorted rays
+        hip.tune_combine(4, 8, 0)
+        m.set_chunk_rays(448)
+        m.set_trace_multiple(2)
+        for sort in (1, 0):
+            m.set_sort_rays(sort)
+            out = m.formod_host(case.geom, rad_in=rad_in)
+            for k in ("rad", "tau", "tp", "np"):
+                x, y = np.asarray(out[k]), np.asarray(ref[k])
+                assert np.array_equal(np.nan_to_num(x, nan=-1.0).view(np.uint8), np.nan_to_num(y, nan=-1.0).view(np.uint8)), (k, "chunks", sort)
     finally:
         hip.tune_combine(-1, 8, 1_000_000)              # back to the default rule
         m.close()
