@@ -53,6 +53,9 @@ char const *jur_last_error(void);
 
 /* sizeof(ctl_t), sizeof(atm_t), sizeof(obs_t), ND, NG the library was built with */
 void jur_abi_sizes(size_t out[5]);
+/* C1, C2, P0, RE (reference jurassic.h:109-126) and the GSL 2.5 values of N_A, k_B, R (used at jr_common.h:330,
+ * 450, 744) the library was built with */
+void jur_abi_constants(double out[7]);
 
 /* Host-side emissivity tables under construction. */
 typedef struct jur_tables jur_tables_t;
@@ -95,10 +98,12 @@ void jur_model_destroy(jur_model_t *m);
  * copy; the caller's atm is not modified (GPU-path behaviour upstream,
  * GPUdrivers.cu:243).  An atmosphere identical to the one on the device is not
  * uploaded again.
- * Ordering: the upload waits for the stream of the model's last
- * jur_formod_device call (whose kernels may still read the old atmosphere), so
- * that stream handle must still be valid; calls enqueued on OTHER streams
- * before that are the caller's to synchronise. */
+ * Ordering: the upload waits for the model's last jur_formod_device call
+ * (whose kernels may still read the old atmosphere) through an event of the
+ * model's own that the call left on the caller's stream -- no handle of the
+ * caller's is kept, the stream may have been destroyed since.  Calls enqueued
+ * on OTHER streams before that one, and launches of a captured graph, are the
+ * caller's to synchronise. */
 int  jur_model_set_atm(jur_model_t *m, atm_t const *atm);
 
 /* Forward model for nr rays, host arrays.  geom[7] = {time, obsz, obslon,
@@ -191,6 +196,12 @@ int  jur_model_set_pencil(jur_model_t *m, long max_rays, int rays_per_group);
  * the channel count is a multiple of four: other group shapes were measured slower than one channel per workgroup.
  * Results do not depend on it (tests/test_parity_gpu.py compares the arrangements bit for bit). */
 void jur_tune_combine(int channels_per_group, int sync_segments, long min_lanes);
+
+/* Frees the process-global state behind formod() / formod_GPU() / formod_pencil(): the lanes (streams, atmosphere,
+ * workspaces, pinned images) and the emissivity tables loaded by the first call.  Upstream keeps its counterparts for
+ * the life of the process (GPUdrivers.cu:263-273, 309; jr_common.h:60-78).  Waits for calls in flight; returns the
+ * number of lanes freed (0: nothing was initialised).  The next formod() loads the tables again. */
+int  jur_dropin_finalize(void);
 
 /* Summed duration in ms and launch count of each kernel since the last query,
  * measured with HIP events on the launch stream while timing is enabled:

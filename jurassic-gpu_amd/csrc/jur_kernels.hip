@@ -42,6 +42,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <cstdlib>
+#include <mutex>
 #include "jur_internal.h"
 
 #define NLOS JUR_NLOS
@@ -88,6 +89,34 @@ __device__ __forceinline__ double div_finite(double a, double b) {
 }
 __device__ __forceinline__ double lip_finite(double x0, double y0, double x1, double y1, double x) {
   return y0 + div_finite((x - x0) * (y1 - y0), x1 - x0);
+}
+
+// ---- arithmetic of the strict-table path (round 3) -------------------------------------------------------------
+// The contract is 1e-6 relative on the radiances and the suite holds 1e-9; bit-identity with the reference's
+// divisions is not needed to stay 1e3 .. 1e6 times inside that, and it is what 40 % of the look-up's fp64 work went
+// into.  On tables whose axes and curves are strictly increasing (no zero-width bracket) the look-up uses:
+//   div_fast   a / b as a * r, r = rcp(b) refined by ONE Newton step: v_rcp_f64 is good to 2^-23 or better, the step
+//              squares that -- the quotient is good to ~2^-46 of itself, and it is the INCREMENT of an interpolation
+//              (at most a bracket width), so the interpolated value is good to a few 1e-15 of itself; 4 instructions
+//              with one v_rcp_f64 instead of 8;
+//   lip_mulr   the p and T blends as y0 + ((x - x0) (y1 - y0)) r with r = RN(1 / (x1 - x0)): two roundings instead
+//              of the division's one, 1 instruction instead of 3;
+//   the path transmittance is carried as tau <- 1 - eps_t instead of tau <- tau * ((1 - eps_t) / tau): the same
+//   number up to the two roundings the reference spends on dividing by tau and multiplying with it again (the
+//   radiance update divides the products over the gases of consecutive segments instead: one division per
+//   (channel, segment) in place of one per (channel, gas, segment)).
+// tests/test_kat_gpu.py holds this path against the bit-exact ones (modes 0 .. 2), which stay the known-answer
+// reference against the oracle.
+__device__ __forceinline__ double div_fast(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+  return a * r;
+}
+__device__ __forceinline__ double lip_fast(double x0, double y0, double x1, double y1, double x) {
+  return y0 + div_fast((x - x0) * (y1 - y0), x1 - x0);
+}
+__device__ __forceinline__ double lip_mulr(double x0, double y0, double y1, double x, double r) {
+  return y0 + ((x - x0) * (y1 - y0)) * r;
 }
 
 // bracket search on an ascending or descending axis (jr_common.h:87-104)
@@ -476,7 +505,10 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
     }
     ++np;
     if (NLOS <= np) {  // the reference aborts here (jr_common.h:693-695); flag and clamp
-      atomicOr(status, 1);
+      // a plain store of the one value this path ever reports: the word may live in pinned host memory (the fused
+      // kernel of a package-sized host call writes it across PCIe), where a device atomic needs PCIe atomics
+      // from the platform and is silently dropped without them
+      *reinterpret_cast<volatile int *>(status) = 1;
       np = NLOS - 1;
     }
 
@@ -723,10 +755,17 @@ struct PairDesc {
     if constexpr (LDS) return reinterpret_cast<Crv const *>(jur_lds + JUR_TBLNP * sizeof(Lvl))[k - kbase];
     else return ldg<Crv>(cvb, k);
   }
-  // LDS only: 1/(p[i+1] - p[i]) and 1/(T[k+1] - T[k]), formed by the staging loop
+  // 1/(p[i+1] - p[i]) and 1/(T[k+1] - T[k]): formed by the staging loop (LDS), or here with the same division --
+  // the same doubles either way (the fused kernel reads its descriptors through L1 and has no staged copy)
   unsigned rp_off, rt_off;     // byte offsets of the two reciprocal arrays in the LDS block
-  __device__ __forceinline__ double rp(int i) const { return reinterpret_cast<double const *>(jur_lds + rp_off)[i]; }
-  __device__ __forceinline__ double rt(unsigned k) const { return reinterpret_cast<double const *>(jur_lds + rt_off)[k - kbase]; }
+  __device__ __forceinline__ double rp(int i) const {
+    if constexpr (LDS) return reinterpret_cast<double const *>(jur_lds + rp_off)[i];
+    else return 1. / (lvl(i + 1).p - lvl(i).p);
+  }
+  __device__ __forceinline__ double rt(unsigned k) const {
+    if constexpr (LDS) return reinterpret_cast<double const *>(jur_lds + rt_off)[k - kbase];
+    else return 1. / (crv(k + 1).t - crv(k).t);
+  }
 };
 
 // EXACT look-up: the reference's bisections probe for probe (locate_id jr_common.h:106-114, locate_tbl_id
@@ -791,12 +830,16 @@ __device__ __forceinline__ double ega_eps_exact(jur_view_t const &v, jur_int2 co
 // RCPB (LDS copy present; p and T axes and, as stored in fp32, every curve strictly increasing: no bracket
 // has zero width): the three blends divide by multiplying with the reciprocal bracket widths staged in
 // LDS (div_rcp), the other nine divisions use div_finite.
-template <bool LDS, bool RCPB>
+// RCPB is the strict-table arithmetic described at div_fast; with PATH the function returns the NEW path
+// transmittance (1 - eps_t, or tau where the reference's look-up answers 1) instead of the segment's
+// transmittance (1 - eps_t) / tau -- what the kernels carry and write; the known-answer hook asks for the quotient.
+template <bool LDS, bool RCPB, bool PATH = false>
 __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 const pr, PairDesc<LDS> const &D, double tau, double t,
                                                double u, double p, unsigned &br, unsigned &ia, unsigned &ib) {
-  static_assert(LDS || !RCPB, "the reciprocal widths live in LDS");
+  static_assert(RCPB || !PATH, "only the strict-table arithmetic carries the path transmittance itself");
+  double const one = PATH ? tau : 1.;          // the look-up's "no change" answer
   if (tau < 1e-9) return 0.;
-  if (pr.a < 2) return 1.;
+  if (pr.a < 2) return one;
   void const *const ueb = v.ue;
   int ipr = min((int)(br & 0xffu), pr.a - 2);
   Lvl l0 = D.lvl(ipr), l1 = D.lvl(ipr + 1);
@@ -805,7 +848,7 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
     while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = D.lvl(ipr + 1); }
   }
   br = (br & ~0xffu) | (unsigned)ipr;
-  if (l0.nt < 2 || l1.nt < 2) return 1.;
+  if (l0.nt < 2 || l1.nt < 2) return one;
   unsigned const k0 = (unsigned)l0.c0, k1 = (unsigned)l1.c0;
   int it0 = min((int)((br >> 8) & 0xffu), l0.nt - 2), it1 = min((int)((br >> 16) & 0xffu), l1.nt - 2);
   {
@@ -817,7 +860,7 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
       while (t >= c11.t && it1 < l1.nt - 2) { ++it1; c10 = c11; c11 = D.crv(k1 + it1 + 1); }
     }
     br = (unsigned)ipr | ((unsigned)it0 << 8) | ((unsigned)it1 << 16);
-    if (c00.nu < 2 || c01_.nu < 2 || c10.nu < 2 || c11.nu < 2) return 1.;
+    if (c00.nu < 2 || c01_.nu < 2 || c10.nu < 2 || c11.nu < 2) return one;
   }
   // RCPB clamps with min/max, which would turn a NaN into 0: a NaN among the inputs (the tables hold none) is
   // answered here with what the comparisons of c01 would have handed through
@@ -849,13 +892,13 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         double const ya = kkey<false>(a[k]), yb = kkey<false>(b[k]);    // ... which serve get_eps's search as its keys
-        x[k] = lip_finite(ka[k], ya, kb[k], yb, eps) + u;
+        x[k] = lip_fast(ka[k], ya, kb[k], yb, eps) + u;
         ka[k] = ya; kb[k] = yb;
       }
 #pragma unroll
       for (int k = 0; k < 2; k++) seek_curve_keys<false, true>(ueb, e0[k], n[k], x[k], i[k], a[k], b[k], ka[k], kb[k]);
 #pragma unroll
-      for (int k = 0; k < 2; k++) ec[k] = c01_num(lip_finite(ka[k], (double)a[k].eps, kb[k], (double)b[k].eps, x[k]));
+      for (int k = 0; k < 2; k++) ec[k] = c01_num(lip_fast(ka[k], (double)a[k].eps, kb[k], (double)b[k].eps, x[k]));
     } else {
 #pragma unroll
       for (int k = 0; k < 2; k++) seek_curve<true>(ueb, e0[k], n[k], eps, i[k], a[k], b[k]);
@@ -869,7 +912,7 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
     unsigned const last = (unsigned)i[0] | ((unsigned)i[1] << 16);
     if (h) ib = last; else ia = last;
     double e;
-    if constexpr (RCPB) e = c01_num(lip_rcp(ca.t, ec[0], cb.t, ec[1], t, D.rt(kc)));
+    if constexpr (RCPB) e = c01_num(lip_mulr(ca.t, ec[0], ec[1], t, D.rt(kc)));
     else e = c01(lip(ca.t, ec[0], cb.t, ec[1], t));
     if (h) eps_p1 = e; else eps_p0 = e;
   }
@@ -878,7 +921,9 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
     // keeps the kernel at 7 waves per SIMD with the keys held as doubles
     int q = ipr;
     asm volatile("" : "+v"(q));
-    return div_finite(1. - c01_num(lip_rcp(D.lvl(q).p, eps_p0, D.lvl(q + 1).p, eps_p1, p, D.rp(q))), tau);
+    double const tau_new = 1. - c01_num(lip_mulr(D.lvl(q).p, eps_p0, eps_p1, p, D.rp(q)));
+    if constexpr (PATH) return tau_new;
+    else return div_finite(tau_new, tau);
   }
   return (1. - c01(lip(l0.p, eps_p0, l1.p, eps_p1, p))) / tau;
 }
@@ -889,10 +934,15 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
 // the four curve emissivities are exchanged with DPP moves and every lane forms the blends -- the operations of
 // ega_eps_warm<false, false> in the same order, hence the same doubles.  State: br as there, ix = this lane's
 // position in its own curve.
+// FAST: the strict-table arithmetic of ega_eps_warm<.., true, true> (div_fast, lip_mulr with the reciprocal widths
+// formed here by division -- the same doubles as the staged ones), returning the new path transmittance: the same
+// doubles as the batched kernel.  Otherwise the reference's arithmetic, returning the segment's transmittance.
+template <bool FAST>
 __device__ __forceinline__ double ega_eps_warm_quad(jur_view_t const &v, jur_int2 const pr, PairDesc<false> const &D, double tau,
                                                     double t, double u, double p, unsigned &br, unsigned &ix) {
+  double const one = FAST ? tau : 1.;
   if (tau < 1e-9) return 0.;
-  if (pr.a < 2) return 1.;
+  if (pr.a < 2) return one;
   void const *const ueb = v.ue;
   int ipr = min((int)(br & 0xffu), pr.a - 2);
   Lvl l0 = D.lvl(ipr), l1 = D.lvl(ipr + 1);
@@ -901,7 +951,7 @@ __device__ __forceinline__ double ega_eps_warm_quad(jur_view_t const &v, jur_int
     while (p >= l1.p && ipr < pr.a - 2) { ++ipr; l0 = l1; l1 = D.lvl(ipr + 1); }
   }
   br = (br & ~0xffu) | (unsigned)ipr;
-  if (l0.nt < 2 || l1.nt < 2) return 1.;
+  if (l0.nt < 2 || l1.nt < 2) return one;
   unsigned const k0 = (unsigned)l0.c0, k1 = (unsigned)l1.c0;
   int it0 = min((int)((br >> 8) & 0xffu), l0.nt - 2), it1 = min((int)((br >> 16) & 0xffu), l1.nt - 2);
   Crv c00 = D.crv(k0 + it0), c01_ = D.crv(k0 + it0 + 1), c10 = D.crv(k1 + it1), c11 = D.crv(k1 + it1 + 1);
@@ -912,7 +962,7 @@ __device__ __forceinline__ double ega_eps_warm_quad(jur_view_t const &v, jur_int
     while (t >= c11.t && it1 < l1.nt - 2) { ++it1; c10 = c11; c11 = D.crv(k1 + it1 + 1); }
   }
   br = (unsigned)ipr | ((unsigned)it0 << 8) | ((unsigned)it1 << 16);
-  if (c00.nu < 2 || c01_.nu < 2 || c10.nu < 2 || c11.nu < 2) return 1.;
+  if (c00.nu < 2 || c01_.nu < 2 || c10.nu < 2 || c11.nu < 2) return one;
   int const q = threadIdx.x & 3;
   Crv const mine = (q == 0) ? c00 : (q == 1) ? c01_ : (q == 2) ? c10 : c11;
   unsigned const e0 = (unsigned)mine.e0;
@@ -921,15 +971,29 @@ __device__ __forceinline__ double ega_eps_warm_quad(jur_view_t const &v, jur_int
   Ue a, b;
   ld_pair(ueb, e0 + i, a, b);
   double const eps = 1 - tau;
-  seek_curve<true>(ueb, e0, n, eps, i, a, b);
-  double const x = lip((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps) + u;
-  seek_curve<false>(ueb, e0, n, x, i, a, b);
-  double const ec = c01(lip((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, x));
-  ix = (unsigned)i;
-  double const ec0 = quad_bcast<0>(ec), ec1 = quad_bcast<1>(ec), ec2 = quad_bcast<2>(ec), ec3 = quad_bcast<3>(ec);
-  double const eps_p0 = c01(lip(c00.t, ec0, c01_.t, ec1, t));
-  double const eps_p1 = c01(lip(c10.t, ec2, c11.t, ec3, t));
-  return (1. - c01(lip(l0.p, eps_p0, l1.p, eps_p1, p))) / tau;
+  if constexpr (FAST) {
+    bool const nan_in = (tau != tau || t != t || u != u || p != p);   // as ega_eps_warm: min/max clamps below
+    seek_curve<true>(ueb, e0, n, eps, i, a, b);
+    double const x = lip_fast((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps) + u;
+    seek_curve<false>(ueb, e0, n, x, i, a, b);
+    double const ec = c01_num(lip_fast((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, x));
+    ix = (unsigned)i;
+    double const ec0 = quad_bcast<0>(ec), ec1 = quad_bcast<1>(ec), ec2 = quad_bcast<2>(ec), ec3 = quad_bcast<3>(ec);
+    double const eps_p0 = c01_num(lip_mulr(c00.t, ec0, ec1, t, 1. / (c01_.t - c00.t)));
+    double const eps_p1 = c01_num(lip_mulr(c10.t, ec2, ec3, t, 1. / (c11.t - c10.t)));
+    double const tau_new = 1. - c01_num(lip_mulr(l0.p, eps_p0, eps_p1, p, 1. / (l1.p - l0.p)));
+    return nan_in ? __builtin_nan("") : tau_new;
+  } else {
+    seek_curve<true>(ueb, e0, n, eps, i, a, b);
+    double const x = lip((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps) + u;
+    seek_curve<false>(ueb, e0, n, x, i, a, b);
+    double const ec = c01(lip((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, x));
+    ix = (unsigned)i;
+    double const ec0 = quad_bcast<0>(ec), ec1 = quad_bcast<1>(ec), ec2 = quad_bcast<2>(ec), ec3 = quad_bcast<3>(ec);
+    double const eps_p0 = c01(lip(c00.t, ec0, c01_.t, ec1, t));
+    double const eps_p1 = c01(lip(c10.t, ec2, c11.t, ec3, t));
+    return (1. - c01(lip(l0.p, eps_p0, l1.p, eps_p1, p))) / tau;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -962,30 +1026,47 @@ __device__ __forceinline__ double pow_const(double lnr_hi, double lnr_lo, double
   return __builtin_fma(e, pl, e);
 }
 
-__device__ __forceinline__ double ctm_h2o(jur_chan_t const &ch, double p, double t, double q, double u) {
+// 1 / t for the continua of one segment: 296/T, 0.7193876/T, 273/T and 1/T (jr_common.h:352-355, 374, 388) share
+// it as multiplications.  rcp + two Newton steps: within an ulp of the correctly rounded reciprocal, so every product
+// below is within ~2 ulp of the reference's quotient -- 1e-16 relative where the contract is 1e-6 -- for 5
+// instructions instead of 3 .. 4 full divisions (~45).  (Round 2 measured the bit-identical form of this sharing
+// slower because of two spilled registers; without the correctly-rounded residual steps it is not.)
+__device__ __forceinline__ double rcp_t(double t) {
+  double r = __builtin_amdgcn_rcp(t);
+  r = __builtin_fma(r, __builtin_fma(-t, r, 1.0), r);
+  return __builtin_fma(r, __builtin_fma(-t, r, 1.0), r);
+}
+
+// tanh(x) for the x = 0.7193876 nu / T of the H2O continuum (jr_common.h:354): (1 - e) / (1 + e) with
+// e = exp(-2x) -- one exp and one division instead of the library's tanh (which branches on the size of x and
+// costs about twice as much).  1 - e loses log2(1 / 2x) bits to cancellation: used for nu >= 100 cm^-1, where
+// x >= 0.07 for any T <= 1000 K (relative error <= 2e-15); channels below that take the library function.
+__device__ __forceinline__ double tanh_pos(double x) {
+  double const e = exp(-2. * x);
+  return div_finite(1. - e, 1. + e);
+}
+
+__device__ __forceinline__ double ctm_h2o(jur_chan_t const &ch, double p, double t, double rt, double q, double u) {
   double const y = div_const<T36_DEN>(296. - t);
   double const ctwslf = ch.h2o_sc * pow_const(ch.h2o_lnr_hi, ch.h2o_lnr_lo, y);
-  double const a1 = ch.nu * u * tanh(.7193876 / t * ch.nu);
-  double const a2 = 296. / t;
+  double const x = .7193876 * rt * ch.nu;
+  double const a1 = ch.nu * u * ((ch.nu >= 100.) ? tanh_pos(x) : tanh(x));
+  double const a2 = 296. * rt;
   double const a3 = div_const<P0_DEN>(p) * (q * ctwslf + (1 - q) * ch.h2o_ctwfrn) * 1e-20;
   return a1 * a2 * a3;
 }
 
-// (Letting the quotients by the same temperature -- 296/T, 0.7193876/T, 273/T, 1/T -- share one reciprocal, as the
-// tracer does for its common denominators, was measured: bit-identical, five v_rcp_f64 fewer, and slower -- 0.37 ->
-// 0.44 ms per 1e5 nadir rays, 18.2 -> 18.3 ms per 1e6 limb rays: two more spilled registers in a kernel that waits on
-// its dependent chains, not on instruction issue.)
-__device__ __forceinline__ double ctm_n2(jur_chan_t const &ch, double p, double t) {
+__device__ __forceinline__ double ctm_n2(jur_chan_t const &ch, double p, double t, double rt) {
   double const q_n2 = 0.79, t0 = 273, tr = 296;
-  double const pr = div_const<P0_DEN>(p);
-  return 0.1 * pr * pr * (t0 / t) * (t0 / t) * exp(ch.n2_beta * (1 / tr - 1 / t)) * q_n2 * ch.n2_b
+  double const pr = div_const<P0_DEN>(p), s = t0 * rt;
+  return 0.1 * pr * pr * s * s * exp(ch.n2_beta * (1 / tr - rt)) * q_n2 * ch.n2_b
          * (q_n2 + (1 - q_n2) * (1.294 - div_const<TR_DEN>(0.4545 * t)));
 }
 
-__device__ __forceinline__ double ctm_o2(jur_chan_t const &ch, double p, double t) {
+__device__ __forceinline__ double ctm_o2(jur_chan_t const &ch, double p, double t, double rt) {
   double const q_o2 = 0.21, t0 = 273, tr = 296;
-  double const pr = div_const<P0_DEN>(p);
-  return 0.1 * pr * pr * (t0 / t) * (t0 / t) * exp(ch.o2_beta * (1 / tr - 1 / t)) * q_o2 * ch.o2_b;
+  double const pr = div_const<P0_DEN>(p), s = t0 * rt;
+  return 0.1 * pr * pr * s * s * exp(ch.o2_beta * (1 / tr - rt)) * q_o2 * ch.o2_b;
 }
 
 __device__ __forceinline__ double planck_src(double const *__restrict__ sr, double t) {
@@ -996,6 +1077,16 @@ __device__ __forceinline__ double planck_src(double const *__restrict__ sr, doub
   // st1 - st0 is exactly 0.25, so the interpolation's division is the exact multiplication by 4
   double const st0 = 100 + 0.25 * (double)it;
   return sr[it] + (t - st0) * (sr[it + 1] - sr[it]) * 4.0;
+}
+
+// Transmittance of all gases over ONE segment (apply_ega_core's product of the per-gas segment transmittances,
+// jr_common.h:270-280) from the products of the gases' PATH transmittances after this segment (pcur) and after
+// the previous one (pprev): one division per (channel, segment) instead of one per gas.  A gas whose path has
+// gone opaque (path transmittance 0: jr_common.h:239 answers 0 from there on) makes pcur, and from the next segment
+// pprev, 0: the reference's product is 0 there too.  (A pprev below 1e-280 -- twenty gases each within a hair of
+// opaque -- is treated like 0: the ray's own transmittance is below it, nothing it could still add is representable.)
+__device__ __forceinline__ double segment_tau_gas(double pcur, double pprev) {
+  return (pprev > 1e-280) ? div_finite(pcur, pprev) : 0.;
 }
 
 // radiance update of one segment (new_obs_core, jr_common.h:293-300)
@@ -1092,11 +1183,11 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
       if (ip + 1 < np) { p_next = ldg<double>(los_p + o + R, r); t_next = ldg<double>(los_t + o + R, r); }
     } else { p = ldg<double>(los_p + o, r); t = ldg<double>(los_t + o, r); }
     double const u = ldg<double>(los_u + o, r);
-    double eps;
-    if constexpr (WARM) eps = ega_eps_warm<LDS, RCPB>(v, pd, D, tau_path, t, u, p, br, ia, ib);
-    else eps = ega_eps_exact<LDS>(v, pd, D, tau_path, t, u, p);
-    tau_path *= eps;
-    *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)((unsigned)r * 8u)) = eps;
+    // what is carried and written is the gas's transmittance of the path up to and including this segment
+    if constexpr (RCPB) tau_path = ega_eps_warm<LDS, true, true>(v, pd, D, tau_path, t, u, p, br, ia, ib);
+    else if constexpr (WARM) tau_path *= ega_eps_warm<LDS, false>(v, pd, D, tau_path, t, u, p, br, ia, ib);
+    else tau_path *= ega_eps_exact<LDS>(v, pd, D, tau_path, t, u, p);
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)((unsigned)r * 8u)) = tau_path;
   }
 }
 
@@ -1131,7 +1222,7 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
              do_n2 = (v.fourbit & 2) && ch.n2_on, do_o2 = (v.fourbit & 1) && ch.o2_on;
   size_t const oidx = (size_t)ray * nd + d;
   bool const masked = !isfinite(c.rad[oidx]);
-  double rad = 0.0, tau = 1.0;
+  double rad = 0.0, tau = 1.0, pprev = 1.0;
   int const np = c.np[r];
   unsigned has_table = 0;                              // gases with a table for this channel (uniform)
   for (int g = 0; g < ng && g < 32; g++) has_table |= (v.pair[g * nd + d].a >= 2 ? 1u : 0u) << g;
@@ -1141,12 +1232,15 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
     double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
     double beta_ds = L(f_k) * ds;
     if (do_co2) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
-    if (do_h2o) beta_ds += ctm_h2o(ch, p, t, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
-    if (do_n2) beta_ds += ctm_n2(ch, p, t) * ds;
-    if (do_o2) beta_ds += ctm_o2(ch, p, t) * ds;
-    double tau_gas = 1.0;
+    double const rt = rcp_t(t);
+    if (do_h2o) beta_ds += ctm_h2o(ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
+    if (do_n2) beta_ds += ctm_n2(ch, p, t, rt) * ds;
+    if (do_o2) beta_ds += ctm_o2(ch, p, t, rt) * ds;
+    double pcur = 1.0;
     for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
-      if ((has_table >> g) & 1u) tau_gas *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
+      if ((has_table >> g) & 1u) pcur *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
+    double const tau_gas = segment_tau_gas(pcur, pprev);
+    pprev = pcur;
     new_obs_step(tau_gas, beta_ds, planck_src(sr, t), rad, tau);
   }
   ray_epilogue(sr, ch.nu, c.tsurf[r], v.write_bbt, rad, tau);
@@ -1200,7 +1294,7 @@ __global__ __launch_bounds__(512, 6) void jur_combine_group_kernel(jur_view_t v,
              do_n2 = (v.fourbit & 2) && ch.n2_on, do_o2 = (v.fourbit & 1) && ch.o2_on;
   size_t const oidx = (size_t)ray * nd + dd;
   bool const masked = live && !isfinite(c.rad[oidx]);
-  double rad = 0.0, tau = 1.0;
+  double rad = 0.0, tau = 1.0, pprev = 1.0;
   unsigned has_table = 0;
   for (int g = 0; g < ng && g < 32; g++) has_table |= (v.pair[g * nd + dd].a >= 2 ? 1u : 0u) << g;
   for (int ip = 0; ip < npmax; ++ip) {
@@ -1210,12 +1304,15 @@ __global__ __launch_bounds__(512, 6) void jur_combine_group_kernel(jur_view_t v,
       double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
       double beta_ds = L(f_k) * ds;
       if (do_co2) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
-      if (do_h2o) beta_ds += ctm_h2o(ch, p, t, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
-      if (do_n2) beta_ds += ctm_n2(ch, p, t) * ds;
-      if (do_o2) beta_ds += ctm_o2(ch, p, t) * ds;
-      double tau_gas = 1.0;
+      double const rt = rcp_t(t);
+      if (do_h2o) beta_ds += ctm_h2o(ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
+      if (do_n2) beta_ds += ctm_n2(ch, p, t, rt) * ds;
+      if (do_o2) beta_ds += ctm_o2(ch, p, t, rt) * ds;
+      double pcur = 1.0;
       for (int g = 0; g < ng; g++)
-        if ((has_table >> g) & 1u) tau_gas *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
+        if ((has_table >> g) & 1u) pcur *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
+      double const tau_gas = segment_tau_gas(pcur, pprev);
+      pprev = pcur;
       new_obs_step(tau_gas, beta_ds, planck_src(sr, t), rad, tau);
     }
     if ((ip & SYNC) == SYNC) __syncthreads();      // SYNC = 2^k - 1 (0: a barrier after every segment; -1 never matches: none)
@@ -1263,7 +1360,7 @@ __global__ __launch_bounds__(512, 6) void jur_combine_group_kernel(jur_view_t v,
 __host__ __device__ inline long pen_lds_doubles(int nd, int ng, int nw, int RB) {
   long const npair = (long)nd * ng, nfield = JUR_F_K + nw + ng, nchain = RB * npair, nitem = (long)RB * nd;
   long const n1 = nchain > 0 ? nchain : 1;
-  return (long)PEN_RING * nfield * RB + (long)PEN_RINGE * (npair > 0 ? npair : 1) * RB + n1 + 2 * nitem + RB + (5 * n1 + RB + 1) / 2 + 2;
+  return (long)PEN_RING * nfield * RB + (long)PEN_RINGE * (npair > 0 ? npair : 1) * RB + n1 + 3 * nitem + RB + (5 * n1 + RB + 1) / 2 + 2;
 }
 
 struct PenCtl {            // LDS, one per workgroup
@@ -1365,7 +1462,8 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
   double *const st_tau = epsr + (size_t)PEN_RINGE * (npair > 0 ? npair : 1) * RB;
   double *const c_rad = st_tau + (nchain > 0 ? nchain : 1);
   double *const c_tau = c_rad + nitem;
-  double *const tsurf = c_tau + nitem;
+  double *const c_pp = c_tau + nitem;             // product of the gases' path transmittances after the previous segment
+  double *const tsurf = c_pp + nitem;
   unsigned *const st_br = reinterpret_cast<unsigned *>(tsurf + RB);
   unsigned *const st_ix = st_br + (nchain > 0 ? nchain : 1);     // [chain][4]: curve positions (ia, ib packed in [0], [1] without quads)
   int *const npr = reinterpret_cast<int *>(st_ix + 4 * (nchain > 0 ? nchain : 1));
@@ -1374,7 +1472,7 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
   int const nray = (int)((c.n - ray0 < RB) ? c.n - ray0 : RB);    // rays it really has
 
   for (int i = tid; i < nchain; i += blockDim.x) { st_tau[i] = 1.0; st_br[i] = 0; st_ix[4 * i] = st_ix[4 * i + 1] = st_ix[4 * i + 2] = st_ix[4 * i + 3] = 0; }
-  for (int i = tid; i < nitem; i += blockDim.x) { c_rad[i] = 0.0; c_tau[i] = 1.0; }
+  for (int i = tid; i < nitem; i += blockDim.x) { c_rad[i] = 0.0; c_tau[i] = 1.0; c_pp[i] = 1.0; }
   for (int i = tid; i < RB; i += blockDim.x) { npr[i] = (i < nray) ? 0 : 1; tsurf[i] = -999; }   // 1: through, no points
   if (tid == 0) {
     ctl.cnt_trace = 0; ctl.done = 0;
@@ -1473,18 +1571,20 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
         D.l0 = (unsigned)pd.b;
         double const p = slot[JUR_F_P * RB + r], t = slot[JUR_F_T * RB + r], u = slot[(JUR_F_K + v.nw + g) * RB + r];
         double const tau_path = st_tau[e];
-        double eps;
+        double tau_new;                                            // the gas's path transmittance after this segment
         if constexpr (WARM && QUAD) {
           unsigned br = st_br[e], ix = st_ix[4 * e + (lane & 3)];
-          eps = ega_eps_warm_quad(v, pd, D, tau_path, t, u, p, br, ix);
+          if (v.strict_tables) tau_new = ega_eps_warm_quad<true>(v, pd, D, tau_path, t, u, p, br, ix);
+          else tau_new = tau_path * ega_eps_warm_quad<false>(v, pd, D, tau_path, t, u, p, br, ix);
           st_br[e] = br; st_ix[4 * e + (lane & 3)] = ix;
         } else if constexpr (WARM) {
           unsigned br = st_br[e], ia = st_ix[4 * e], ib = st_ix[4 * e + 1];
-          eps = ega_eps_warm<false, false>(v, pd, D, tau_path, t, u, p, br, ia, ib);
+          if (v.strict_tables) tau_new = ega_eps_warm<false, true, true>(v, pd, D, tau_path, t, u, p, br, ia, ib);
+          else tau_new = tau_path * ega_eps_warm<false, false>(v, pd, D, tau_path, t, u, p, br, ia, ib);
           st_br[e] = br; st_ix[4 * e] = ia; st_ix[4 * e + 1] = ib;
-        } else eps = ega_eps_exact<false>(v, pd, D, tau_path, t, u, p);
-        st_tau[e] = tau_path * eps;
-        eslot[pr * RB + r] = eps;
+        } else tau_new = tau_path * ega_eps_exact<false>(v, pd, D, tau_path, t, u, p);
+        st_tau[e] = tau_new;
+        eslot[pr * RB + r] = tau_new;
       }
       if (first_active_lane()) st_rel(&ctl.cnt_ega[w], ip + 1);
     }
@@ -1507,12 +1607,15 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
         double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
         double beta_ds = L(JUR_F_K + ch.window) * ds;
         if ((v.fourbit & 8) && ch.co2_on) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
-        if ((v.fourbit & 4) && ch.h2o_on) beta_ds += ctm_h2o(ch, p, t, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
-        if ((v.fourbit & 2) && ch.n2_on) beta_ds += ctm_n2(ch, p, t) * ds;
-        if ((v.fourbit & 1) && ch.o2_on) beta_ds += ctm_o2(ch, p, t) * ds;
-        double tau_gas = 1.0;
+        double const rt = rcp_t(t);
+        if ((v.fourbit & 4) && ch.h2o_on) beta_ds += ctm_h2o(ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
+        if ((v.fourbit & 2) && ch.n2_on) beta_ds += ctm_n2(ch, p, t, rt) * ds;
+        if ((v.fourbit & 1) && ch.o2_on) beta_ds += ctm_o2(ch, p, t, rt) * ds;
+        double pcur = 1.0;
         for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
-          if (v.pair[g * nd + d].a >= 2) tau_gas *= eslot[(d * ng + g) * RB + r];
+          if (v.pair[g * nd + d].a >= 2) pcur *= eslot[(d * ng + g) * RB + r];
+        double const tau_gas = segment_tau_gas(pcur, c_pp[i]);
+        c_pp[i] = pcur;
         double rad = c_rad[i], tau = c_tau[i];
         new_obs_step(tau_gas, beta_ds, planck_src(v.sr + (size_t)d * TBLNS, t), rad, tau);
         c_rad[i] = rad;
@@ -1756,7 +1859,7 @@ __global__ __launch_bounds__(256) void jur_kat_ega_kernel(jur_view_t v, int g, i
   if (pd.a >= 2) stage_pair<LDS, RCPB>(v, pd, D);       // uniform branch; stage_pair ends in a barrier
   unsigned br = 0, ia = 0, ib = 0;
   auto one = [&](long i) {
-    if constexpr (WARM) out[i] = ega_eps_warm<LDS, RCPB>(v, pd, D, tau[i], t[i], u[i], p[i], br, ia, ib);
+    if constexpr (WARM) out[i] = ega_eps_warm<LDS, RCPB, false>(v, pd, D, tau[i], t[i], u[i], p[i], br, ia, ib);
     else out[i] = ega_eps_exact<LDS>(v, pd, D, tau[i], t[i], u[i], p[i]);
   };
   if (chain) {
@@ -1777,9 +1880,10 @@ __global__ __launch_bounds__(256) void jur_kat_continua_kernel(jur_view_t v, int
   if (i >= n) return;
   jur_chan_t const ch = v.chan[d];
   out[i] = ch.co2_on ? ctm_co2(ch, p[i], t[i], u_co2[i]) : 0.;
-  out[n + i] = ch.h2o_on ? ctm_h2o(ch, p[i], t[i], q[i], u_h2o[i]) : 0.;
-  out[2 * n + i] = ch.n2_on ? ctm_n2(ch, p[i], t[i]) : 0.;
-  out[3 * n + i] = ch.o2_on ? ctm_o2(ch, p[i], t[i]) : 0.;
+  double const rt = rcp_t(t[i]);
+  out[n + i] = ch.h2o_on ? ctm_h2o(ch, p[i], t[i], rt, q[i], u_h2o[i]) : 0.;
+  out[2 * n + i] = ch.n2_on ? ctm_n2(ch, p[i], t[i], rt) : 0.;
+  out[3 * n + i] = ch.o2_on ? ctm_o2(ch, p[i], t[i], rt) : 0.;
 }
 
 // what == 0: src = source function at t = a[i]; (rad, tau) updated by one segment with tau_gas = b[i], beta_ds = c[i]
@@ -1854,13 +1958,16 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
   int const block = 256;
   int const nrb = (c->n + block - 1) / block;
   unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * v->nd);
-  if (g_combine_group < 0) {                       // first launch: the environment may override the defaults (A/B switch)
+  static std::once_flag env_once;                  // first launch: the environment may override the defaults (A/B
+  std::call_once(env_once, [] {                    // switch); once, whichever lane's thread comes first
+    if (g_combine_group >= 0) return;              // jur_tune_combine has spoken already
     g_combine_group = getenv("JUR_COMBINE_GROUP") ? atoi(getenv("JUR_COMBINE_GROUP")) : 4;
     g_combine_forced = getenv("JUR_COMBINE_GROUP") != NULL;
     if (g_combine_group > 6) g_combine_group = 6;
     if (getenv("JUR_COMBINE_SYNC")) g_combine_sync = atoi(getenv("JUR_COMBINE_SYNC"));
     if (getenv("JUR_COMBINE_MIN_LANES")) g_combine_min_lanes = atol(getenv("JUR_COMBINE_MIN_LANES"));
-  }
+  });
+  if (g_combine_group < 0) g_combine_group = 4;
   int const group = g_combine_group, sync = g_combine_sync;
   // grouped only when the launch fills the chip several times over -- below that a call is as long as its longest
   // chain, and barriers between wavefronts lengthen it (nadir_1e5, 3e5 lanes: 0.66 against 0.37 ms) -- and, by
@@ -1991,13 +2098,21 @@ extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int
   hipStream_t s = (hipStream_t)stream;
   int const atm_cap = pencil_atm_cap(v);
   long const lds_all = lds + 8L * (7 + v->ng + v->nw) * atm_cap;
-  static bool raised = false;      // dynamic LDS beyond 64 KB needs the attribute once per kernel
-  if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    raised = true;
+  {  // dynamic LDS beyond 64 KB needs the attribute once per kernel AND per device (models may live on several
+     // GPUs of one process, their lanes launch from several threads)
+    static std::mutex mu;
+    static unsigned long long raised = 0;                 // one bit per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return (int)hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!((raised >> dev) & 1ull)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e != hipSuccess) { (void)hipGetLastError(); if (lds_all > 64 * 1024) return (int)e; }
+      else raised |= 1ull << dev;
+    }
   }
   if (v->sorted_tables) {
     if (quad) hipLaunchKernelGGL((jur_pencil_kernel<true, true>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);

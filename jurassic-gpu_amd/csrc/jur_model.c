@@ -71,8 +71,12 @@ struct jur_model {
   hipStream_t stream2;          /* copies that run beside the kernels of `stream` */
   hipEvent_t ev_mask, ev_trace;
   int host_call;                /* 1 while jur_formod_host drives jur_formod_device: record / wait for the events above */
-  void *last_stream;            /* stream of the last jur_formod_device call (see jur_model_set_atm) */
-  int have_last_stream;
+  hipEvent_t ev_done;           /* recorded on the caller's stream at the end of every jur_formod_device call: what a
+                                   later upload of the atmosphere waits for (no handle of the caller's is kept) */
+  int have_done;
+  /* field-of-view convolution of device arrays: grow-only scratch and its own status word */
+  double *d_fov;
+  long fov_cap;
   /* small calls: the fused kernel (jur_pencil_kernel) instead of sort + three batched kernels */
   long pencil_rays;             /* calls of up to this many rays take it (0: never)             */
   int pencil_rb;                /* rays per workgroup (0: chosen from the call size)            */
@@ -118,7 +122,8 @@ static int create_streams(jur_model_t *m) {
       hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_mask, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&m->ev_trace, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&m->ev_trace, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming) != hipSuccess) {
     jur_set_error("cannot create the model's streams and events");
     return JUR_EHIP;
   }
@@ -252,7 +257,7 @@ void jur_model_destroy(jur_model_t *m) {
   (void)hipSetDevice(m->device);
   if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_lvl = m->d_crv = m->d_ue = NULL;
   void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_lvl, m->d_crv, m->d_ue, m->d_atm, m->d_order, m->d_sort_tmp,
-                  m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np};
+                  m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np, m->d_fov};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
     if (ptrs[i]) (void)hipFree(ptrs[i]);
   if (m->h_io) (void)hipHostFree(m->h_io);
@@ -263,6 +268,7 @@ void jur_model_destroy(jur_model_t *m) {
   if (m->stream2) (void)hipStreamDestroy(m->stream2);
   if (m->ev_mask) (void)hipEventDestroy(m->ev_mask);
   if (m->ev_trace) (void)hipEventDestroy(m->ev_trace);
+  if (m->ev_done) (void)hipEventDestroy(m->ev_done);
   if (m->evpool) {
     for (int i = 0; i < 2 * JUR_MAX_TIMED; i++) (void)hipEventDestroy(m->evpool[i]);
     free(m->evpool);
@@ -342,12 +348,12 @@ static int upload_atm_rows(jur_model_t *m, double const *h, long n) {
     HIPCHK(hipMalloc(&m->d_atm, sizeof(double) * (nrow + 1) * (size_t)n));   /* + one row for atm_pslope */
     m->atm_cap = n;
   }
-  /* Kernels of an earlier jur_formod_device call may still be reading the atmosphere on the CALLER's stream:
-   * wait for that stream first (the handle must still be valid -- see jurassic_hip.h).  Work on the model's own
-   * stream (jur_formod_host, the drop-in entry) is ordered by the stream itself. */
-  if (m->have_last_stream && (hipStream_t)m->last_stream != m->stream) {
-    HIPCHK(hipStreamSynchronize((hipStream_t)m->last_stream));
-    m->have_last_stream = 0;
+  /* Kernels of an earlier jur_formod_device call may still be reading the atmosphere on the CALLER's stream: wait
+   * for the event that call left behind on it.  The event is the model's own; the caller's stream may have been
+   * destroyed since (destruction completes its work, and the event with it). */
+  if (m->have_done) {
+    HIPCHK(hipEventSynchronize(m->ev_done));
+    m->have_done = 0;
   }
   HIPCHK(hipMemcpyAsync(m->d_atm, h, sizeof(double) * nrow * (size_t)n, hipMemcpyHostToDevice, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
@@ -601,6 +607,17 @@ static int pencil_rays_per_group(jur_model_t const *m, long nr) {
   return jurk_pencil_lds_bytes(&m->view, rb) > 0 ? rb : 0;
 }
 
+/* Leaves the model's event behind the work just enqueued on the caller's stream (see upload_atm_rows).  Not while
+ * the stream is being captured into a graph: the graph's launches are the caller's to order against later uploads. */
+static int record_done(jur_model_t *m, hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
+  if (st != hipStreamCaptureStatusNone) return JUR_OK;
+  HIPCHK(hipEventRecord(m->ev_done, s));
+  m->have_done = 1;
+  return JUR_OK;
+}
+
 int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_rad, double *d_tau, double *d_tp,
                       int *d_np, int *d_status, void *stream) {
   if (!m || nr < 0) { jur_set_error("formod_device: bad arguments"); return JUR_EINVAL; }
@@ -609,8 +626,6 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
   if (m->view.atm_np < 2) { jur_set_error("formod_device: no atmosphere set"); return JUR_EINVAL; }
   HIPCHK(hipSetDevice(m->device));
   hipStream_t s = (hipStream_t)stream;
-  m->last_stream = stream;
-  m->have_last_stream = 1;
   int const rb = pencil_rays_per_group(m, nr);
   if (rb > 0) {
     /* a package-sized call: the whole path in one launch, a workgroup per rb rays, LOS state in LDS */
@@ -630,7 +645,7 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     if (e) { jur_set_error("fused kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
     if (ti >= 0) HIPCHK(hipEventRecord(m->evpool[2 * ti + 1], s));
     if (m->host_call) HIPCHK(hipEventRecord(m->ev_trace, s));
-    return JUR_OK;
+    return record_done(m, s);
   }
   int rc = ensure_workspace(m, nr);
   if (rc) return rc;
@@ -696,7 +711,7 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     }
   }
 #undef TIMED
-  return JUR_OK;
+  return record_done(m, s);
 }
 
 /* ---- host entry ----------------------------------------------------------------- */
@@ -953,22 +968,33 @@ int jur_fov_apply_device(jur_model_t *m, long nr, double const *d_time, double c
   hipStream_t s = (hipStream_t)stream;
   int const nd = m->view.nd;
   size_t const vals = (size_t)nr * nd;
-  double *tmp = NULL;                          /* rad0 | tau0 | dz | w : every ray reads the UNconvolved neighbours */
-  HIPCHK(hipMalloc((void **)&tmp, sizeof(double) * (2 * vals + 2 * (size_t)n)));
+  /* scratch kept by the model and only ever grown: rad0 | tau0 | dz | w | status word.  Every ray reads the
+   * UNconvolved neighbours; the status word is this path's own (a forward-model call in flight on another stream
+   * keeps m->d_status to itself), and nothing here allocates or frees per call (hipFree would wait for the whole
+   * device). */
+  long const need = (long)(2 * vals + 2 * (size_t)JUR_NSHAPE + 1);
+  if (need > m->fov_cap) {
+    if (m->d_fov) (void)hipFree(m->d_fov);
+    m->d_fov = NULL; m->fov_cap = 0;
+    HIPCHK(hipMalloc((void **)&m->d_fov, sizeof(double) * (size_t)need));
+    m->fov_cap = need;
+  }
+  double *const tmp = m->d_fov;
+  int *const d_st = (int *)(tmp + 2 * vals + 2 * (size_t)JUR_NSHAPE);
+  int *const h_st = m->h_status + 1;             /* second word of the pinned status block */
   int rc = JUR_OK, status = 0;
   hipError_t e = hipMemcpyAsync(tmp, d_rad, sizeof(double) * vals, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(tmp + vals, d_tau, sizeof(double) * vals, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(tmp + 2 * vals, dz, sizeof(double) * n, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(tmp + 2 * vals + n, w, sizeof(double) * n, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemsetAsync(m->d_status, 0, sizeof(int), s);
+  if (e == hipSuccess) e = hipMemcpyAsync(tmp + 2 * vals + JUR_NSHAPE, w, sizeof(double) * n, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(d_st, 0, sizeof(int), s);
   if (e == hipSuccess)
-    e = (hipError_t)jurk_launch_fov(nr, nd, d_time, d_vpz, tmp, tmp + vals, d_rad, d_tau, nd, n, tmp + 2 * vals, tmp + 2 * vals + n,
-                                    m->d_status, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(m->h_status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s);
+    e = (hipError_t)jurk_launch_fov(nr, nd, d_time, d_vpz, tmp, tmp + vals, d_rad, d_tau, nd, n, tmp + 2 * vals,
+                                    tmp + 2 * vals + JUR_NSHAPE, d_st, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(h_st, d_st, sizeof(int), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) { jur_set_error("jur_fov_apply_device: %s", hipGetErrorString(e)); rc = JUR_EHIP; }
-  else status = *m->h_status;
-  (void)hipFree(tmp);
+  else status = *h_st;
   if (!rc && (status & 2)) { jur_set_error("Cannot apply FOV convolution!"); rc = JUR_EINVAL; }
   return rc;
 }
@@ -1184,7 +1210,7 @@ static jur_model_t *clone_lane(jur_model_t const *m) {
   c->d_io = NULL; c->d_io_np = NULL; c->io_cap = 0;
   c->h_io = NULL; c->h_io_cap = 0; c->h_pkg = NULL; c->h_atm = NULL; c->h_atm_n = 0; c->h_atm_cap = 0; c->h_status = NULL;
   c->stream = NULL; c->stream2 = NULL; c->ev_mask = NULL; c->ev_trace = NULL;
-  c->host_call = 0; c->have_last_stream = 0; c->last_stream = NULL;
+  c->host_call = 0; c->have_done = 0; c->ev_done = NULL; c->d_fov = NULL; c->fov_cap = 0;
   c->timing = 0; c->evpool = NULL; c->evkind = NULL; c->ntimed = 0;
   if (hipSetDevice(c->device) != hipSuccess || create_streams(c) != JUR_OK ||
       hipMalloc((void **)&c->d_status, sizeof(int)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
@@ -1283,6 +1309,29 @@ static void formod_range(ctl_t const *ctl, atm_t *atm, obs_t *obs, int r0, int n
     }
   }
   release_lane(lane);
+}
+
+/* Explicit finalize for the drop-in entry's process-global state (upstream never frees its own,
+ * GPUdrivers.cu:263-273, 309): every lane with its stream, atmosphere, workspace and pinned images, and the tables
+ * of lane 0.  Waits for lanes that are still in a call.  A later formod() initialises again from the files named
+ * by its ctl.  Safe to call twice, before any formod(), and from an atexit handler. */
+int jur_dropin_finalize(void) {
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < g_nlane; i++)
+    while (g_busy[i]) pthread_cond_wait(&g_cond, &g_lock);
+  int const n = g_nlane;
+  for (int i = n - 1; i >= 0; i--) {              /* lane 0 owns the tables the others share: last */
+    if (g_lane[i]) {
+      (void)hipSetDevice(g_lane[i]->device);
+      if (g_lane[i]->stream) (void)hipStreamSynchronize(g_lane[i]->stream);
+      jur_model_destroy(g_lane[i]);
+    }
+    g_lane[i] = NULL;
+  }
+  g_nlane = 0;
+  g_maxlane = 0;
+  pthread_mutex_unlock(&g_lock);
+  return n;
 }
 
 void formod_GPU(ctl_t const *ctl, atm_t *atm, obs_t *obs) { formod_range(ctl, atm, obs, 0, obs ? obs->nr : 0); }

@@ -35,6 +35,13 @@ void jur_abi_sizes(size_t out[5]) {
   out[3] = JUR_ND; out[4] = JUR_NG;
 }
 
+/* the physical constants this build computes with (include/jurassic_abi.h), in the order
+ * C1, C2, P0, RE, N_A, k_B, R: tests hold them against literals of their own */
+void jur_abi_constants(double out[7]) {
+  out[0] = JUR_C1; out[1] = JUR_C2; out[2] = JUR_P0; out[3] = JUR_RE;
+  out[4] = JUR_AVOGADRO; out[5] = JUR_BOLTZMANN; out[6] = JUR_MOLAR_GAS;
+}
+
 /* ---- continuum coefficient data ------------------------------------------- */
 #ifndef CTM_BLOB_PATH
 #error "compile with -DCTM_BLOB_PATH"

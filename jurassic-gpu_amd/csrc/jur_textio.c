@@ -1,6 +1,7 @@
 /* jur_textio.c -- see jur_textio.h */
 #define _GNU_SOURCE
 #include <math.h>
+#include <stddef.h>
 #include <string.h>
 #include <strings.h>
 #include "jur_textio.h"
@@ -44,68 +45,102 @@ double scan_ctl(int argc, char *argv[], char const *varname, int arridx, char co
   return atof(rval);
 }
 
+/* The control block is filled from a table of its keys: one row per key with the member it lands in, its type,
+ * its default ("" = mandatory) and what it is an array over.  Keys, defaults and their order are the file format of
+ * the reference's control files (read_ctl, jurassic.c:920-1022) -- `formod limb.ctl ...` must accept the same files. */
+enum { T_INT, T_DBL, T_STR };
+enum { PER_NONE, PER_GAS, PER_CHANNEL, PER_WINDOW };
+typedef struct {
+  char const *key;
+  int type, per;
+  size_t offset, stride;
+  char const *dflt;
+} ctl_key_t;
+#define ROW(key, type, per, member, dflt) {key, type, per, offsetof(ctl_t, member), 0, dflt}
+#define ROWS(key, type, per, member, dflt) {key, type, per, offsetof(ctl_t, member), sizeof(((ctl_t *)0)->member[0]), dflt}
+static ctl_key_t const ctl_keys[] = {
+  ROW("NG", T_INT, PER_NONE, ng, "0"),
+  ROWS("EMITTER", T_STR, PER_GAS, emitter, ""),
+  ROW("ND", T_INT, PER_NONE, nd, "0"),
+  ROWS("NU", T_DBL, PER_CHANNEL, nu, ""),
+  ROW("NW", T_INT, PER_NONE, nw, "1"),
+  ROWS("WINDOW", T_INT, PER_CHANNEL, window, "0"),
+  ROW("TBLBASE", T_STR, PER_NONE, tblbase, "-"),
+  ROW("HYDZ", T_DBL, PER_NONE, hydz, "-999"),
+  ROW("CTM_CO2", T_INT, PER_NONE, ctm_co2, "1"),
+  ROW("CTM_H2O", T_INT, PER_NONE, ctm_h2o, "1"),
+  ROW("CTM_N2", T_INT, PER_NONE, ctm_n2, "1"),
+  ROW("CTM_O2", T_INT, PER_NONE, ctm_o2, "1"),
+  ROW("IP", T_INT, PER_NONE, ip, "1"),
+  ROW("CZ", T_DBL, PER_NONE, cz, "0"),
+  ROW("CX", T_DBL, PER_NONE, cx, "0"),
+  ROW("REFRAC", T_INT, PER_NONE, refrac, "1"),
+  ROW("RAYDS", T_DBL, PER_NONE, rayds, "10"),
+  ROW("RAYDZ", T_DBL, PER_NONE, raydz, "0.5"),
+  ROW("FOV", T_STR, PER_NONE, fov, "-"),
+  ROW("RETP_ZMIN", T_DBL, PER_NONE, retp_zmin, "-999"),
+  ROW("RETP_ZMAX", T_DBL, PER_NONE, retp_zmax, "-999"),
+  ROW("RETT_ZMIN", T_DBL, PER_NONE, rett_zmin, "-999"),
+  ROW("RETT_ZMAX", T_DBL, PER_NONE, rett_zmax, "-999"),
+  ROWS("RETQ_ZMIN", T_DBL, PER_GAS, retq_zmin, "-999"),
+  ROWS("RETQ_ZMAX", T_DBL, PER_GAS, retq_zmax, "-999"),
+  ROWS("RETK_ZMIN", T_DBL, PER_WINDOW, retk_zmin, "-999"),
+  ROWS("RETK_ZMAX", T_DBL, PER_WINDOW, retk_zmax, "-999"),
+  ROW("WRITE_BBT", T_INT, PER_NONE, write_bbt, "0"),
+  ROW("WRITE_MATRIX", T_INT, PER_NONE, write_matrix, "0"),
+  ROW("FORMOD", T_INT, PER_NONE, formod, "2"),
+  ROW("RFMBIN", T_STR, PER_NONE, rfmbin, "-"),
+  ROW("RFMHIT", T_STR, PER_NONE, rfmhit, "-"),
+  ROWS("RFMXSC", T_STR, PER_GAS, rfmxsc, "-"),
+  ROW("USEGPU", T_INT, PER_NONE, useGPU, "0"),
+  ROW("CHECKMODE", T_INT, PER_NONE, checkmode, "0"),
+  ROW("READ_BINARY", T_INT, PER_NONE, read_binary, "-1"),
+  ROW("WRITE_BINARY", T_INT, PER_NONE, write_binary, "1"),
+  ROW("GPU_SHARED_MEMORY", T_INT, PER_NONE, gpu_nbytes_shared_memory, "0"),
+};
+#undef ROW
+#undef ROWS
+
+/* A continuum is switched off when no channel lies in the spectral range its coefficients cover (the reference
+ * does this while reading the control file, jurassic.c:954-968). */
+static void drop_continua_without_channels(ctl_t *ctl) {
+  struct { int *flag; char const *gas; double lo, hi; int hi_open; } const span[] = {
+    {&ctl->ctm_co2, "CO2", -INFINITY, 4000, 1},      /* nu < 4000        (jr_common.h:318) */
+    {&ctl->ctm_h2o, "H2O", -INFINITY, 20000, 1},     /* nu < 20000       (:345)            */
+    {&ctl->ctm_n2, "N2", 2120, 2605, 0},             /* 2120 .. 2605     (:367)            */
+    {&ctl->ctm_o2, "O2", 1360, 1805, 0},             /* 1360 .. 1805     (:381)            */
+  };
+  for (size_t k = 0; k < sizeof span / sizeof span[0]; k++) {
+    int covered = 0;
+    for (int id = 0; id < ctl->nd && !covered; id++)
+      covered = ctl->nu[id] >= span[k].lo && (span[k].hi_open ? ctl->nu[id] < span[k].hi : ctl->nu[id] <= span[k].hi);
+    if (!covered && *span[k].flag) {
+      *span[k].flag = 0;
+      printf("No frequency in %s range, automatically set CTM_%s = 0\n", span[k].gas, span[k].gas);
+    }
+  }
+}
+
 void read_ctl(int argc, char *argv[], ctl_t *ctl) {
   printf("\nJuelich Rapid Spectral Simulation Code (JURASSIC), MI355X forward model\n(executable: %s)\n\n", argv[0]);
-  ctl->ng = (int)scan_ctl(argc, argv, "NG", -1, "0", NULL);
-  if (ctl->ng < 0 || ctl->ng > JUR_NG) DIE("Set 0 <= NG <= %d", JUR_NG);
-  for (int ig = 0; ig < ctl->ng; ig++) scan_ctl(argc, argv, "EMITTER", ig, "", ctl->emitter[ig]);
-  ctl->nd = (int)scan_ctl(argc, argv, "ND", -1, "0", NULL);
-  if (ctl->nd < 0 || ctl->nd > JUR_ND) DIE("Set 0 <= ND <= %d", JUR_ND);
-  for (int id = 0; id < ctl->nd; id++) ctl->nu[id] = scan_ctl(argc, argv, "NU", id, "", NULL);
-  ctl->nw = (int)scan_ctl(argc, argv, "NW", -1, "1", NULL);
-  if (ctl->nw < 0 || ctl->nw > JUR_NW) DIE("Set 0 <= NW <= %d", JUR_NW);
-  for (int id = 0; id < ctl->nd; id++) ctl->window[id] = (int)scan_ctl(argc, argv, "WINDOW", id, "0", NULL);
-  scan_ctl(argc, argv, "TBLBASE", -1, "-", ctl->tblbase);
-  ctl->hydz = scan_ctl(argc, argv, "HYDZ", -1, "-999", NULL);
-  ctl->ctm_co2 = (int)scan_ctl(argc, argv, "CTM_CO2", -1, "1", NULL);
-  ctl->ctm_h2o = (int)scan_ctl(argc, argv, "CTM_H2O", -1, "1", NULL);
-  ctl->ctm_n2 = (int)scan_ctl(argc, argv, "CTM_N2", -1, "1", NULL);
-  ctl->ctm_o2 = (int)scan_ctl(argc, argv, "CTM_O2", -1, "1", NULL);
-  {  /* continua whose spectral range holds no channel are switched off (jurassic.c:954-968) */
-    int in_co2 = 0, in_h2o = 0, in_n2 = 0, in_o2 = 0;
-    for (int id = 0; id < ctl->nd; id++) {
-      double const nu = ctl->nu[id];
-      in_co2 += (nu < 4000);
-      in_h2o += (nu < 20000);
-      in_n2 += (nu >= 2120 && nu <= 2605);
-      in_o2 += (nu >= 1360 && nu <= 1805);
+  for (size_t k = 0; k < sizeof ctl_keys / sizeof ctl_keys[0]; k++) {
+    ctl_key_t const *row = &ctl_keys[k];
+    int const n = row->per == PER_GAS ? ctl->ng : row->per == PER_CHANNEL ? ctl->nd : row->per == PER_WINDOW ? ctl->nw : 1;
+    for (int i = 0; i < n; i++) {
+      char *const dst = (char *)ctl + row->offset + (size_t)i * row->stride;
+      int const idx = row->per == PER_NONE ? -1 : i;
+      if (row->type == T_STR) scan_ctl(argc, argv, row->key, idx, row->dflt, dst);
+      else if (row->type == T_INT) *(int *)dst = (int)scan_ctl(argc, argv, row->key, idx, row->dflt, NULL);
+      else *(double *)dst = scan_ctl(argc, argv, row->key, idx, row->dflt, NULL);
     }
-    if (0 == in_co2 && ctl->ctm_co2) { ctl->ctm_co2 = 0; printf("No frequency in CO2 range, automatically set CTM_CO2 = 0\n"); }
-    if (0 == in_h2o && ctl->ctm_h2o) { ctl->ctm_h2o = 0; printf("No frequency in H2O range, automatically set CTM_H20 = 0\n"); }
-    if (0 == in_n2 && ctl->ctm_n2) { ctl->ctm_n2 = 0; printf("No frequency in N2 range, automatically set CTM_N2 = 0\n"); }
-    if (0 == in_o2 && ctl->ctm_o2) { ctl->ctm_o2 = 0; printf("No frequency in O2 range, automatically set CTM_O2 = 0\n"); }
+    /* the counts bound the arrays that follow them */
+    if (0 == strcmp(row->key, "NG") && (ctl->ng < 0 || ctl->ng > JUR_NG)) DIE("Set 0 <= NG <= %d", JUR_NG);
+    if (0 == strcmp(row->key, "ND") && (ctl->nd < 0 || ctl->nd > JUR_ND)) DIE("Set 0 <= ND <= %d", JUR_ND);
+    if (0 == strcmp(row->key, "NW") && (ctl->nw < 0 || ctl->nw > JUR_NW)) DIE("Set 0 <= NW <= %d", JUR_NW);
+    if (0 == strcmp(row->key, "CTM_O2")) drop_continua_without_channels(ctl);
+    if (0 == strcmp(row->key, "CHECKMODE"))
+      printf("CHECKMODE = %d (%s)\n", ctl->checkmode, (0 == ctl->checkmode) ? "run" : ((ctl->checkmode > 0) ? "skip" : "obs"));
   }
-  ctl->ip = (int)scan_ctl(argc, argv, "IP", -1, "1", NULL);
-  ctl->cz = scan_ctl(argc, argv, "CZ", -1, "0", NULL);
-  ctl->cx = scan_ctl(argc, argv, "CX", -1, "0", NULL);
-  ctl->refrac = (int)scan_ctl(argc, argv, "REFRAC", -1, "1", NULL);
-  ctl->rayds = scan_ctl(argc, argv, "RAYDS", -1, "10", NULL);
-  ctl->raydz = scan_ctl(argc, argv, "RAYDZ", -1, "0.5", NULL);
-  scan_ctl(argc, argv, "FOV", -1, "-", ctl->fov);
-  ctl->retp_zmin = scan_ctl(argc, argv, "RETP_ZMIN", -1, "-999", NULL);
-  ctl->retp_zmax = scan_ctl(argc, argv, "RETP_ZMAX", -1, "-999", NULL);
-  ctl->rett_zmin = scan_ctl(argc, argv, "RETT_ZMIN", -1, "-999", NULL);
-  ctl->rett_zmax = scan_ctl(argc, argv, "RETT_ZMAX", -1, "-999", NULL);
-  for (int ig = 0; ig < ctl->ng; ig++) {
-    ctl->retq_zmin[ig] = scan_ctl(argc, argv, "RETQ_ZMIN", ig, "-999", NULL);
-    ctl->retq_zmax[ig] = scan_ctl(argc, argv, "RETQ_ZMAX", ig, "-999", NULL);
-  }
-  for (int iw = 0; iw < ctl->nw; iw++) {
-    ctl->retk_zmin[iw] = scan_ctl(argc, argv, "RETK_ZMIN", iw, "-999", NULL);
-    ctl->retk_zmax[iw] = scan_ctl(argc, argv, "RETK_ZMAX", iw, "-999", NULL);
-  }
-  ctl->write_bbt = (int)scan_ctl(argc, argv, "WRITE_BBT", -1, "0", NULL);
-  ctl->write_matrix = (int)scan_ctl(argc, argv, "WRITE_MATRIX", -1, "0", NULL);
-  ctl->formod = (int)scan_ctl(argc, argv, "FORMOD", -1, "2", NULL);
-  scan_ctl(argc, argv, "RFMBIN", -1, "-", ctl->rfmbin);
-  scan_ctl(argc, argv, "RFMHIT", -1, "-", ctl->rfmhit);
-  for (int ig = 0; ig < ctl->ng; ig++) scan_ctl(argc, argv, "RFMXSC", ig, "-", ctl->rfmxsc[ig]);
-  ctl->useGPU = (int)scan_ctl(argc, argv, "USEGPU", -1, "0", NULL);
-  ctl->checkmode = (int)scan_ctl(argc, argv, "CHECKMODE", -1, "0", NULL);
-  printf("CHECKMODE = %d (%s)\n", ctl->checkmode, (0 == ctl->checkmode) ? "run" : ((ctl->checkmode > 0) ? "skip" : "obs"));
-  ctl->read_binary = (int)scan_ctl(argc, argv, "READ_BINARY", -1, "-1", NULL);
-  ctl->write_binary = (int)scan_ctl(argc, argv, "WRITE_BINARY", -1, "1", NULL);
-  ctl->gpu_nbytes_shared_memory = (int)scan_ctl(argc, argv, "GPU_SHARED_MEMORY", -1, "0", NULL);
 }
 
 /* one whitespace-separated number per call; a token that does not parse drops the whole line,

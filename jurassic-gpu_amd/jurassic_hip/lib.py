@@ -150,13 +150,22 @@ class Tables:
         return self
 
 
+def _free_pinned(p):
+    try:
+        lib().jur_host_free(p)
+    except TypeError:                  # interpreter shutdown: the module globals are gone already
+        pass
+
+
 class HostBuffers:
     """The arrays of one jur_formod_host call, allocated once and reused: geom (7, nr), rad/tau (nr, nd),
-    tp (3, nr), np (nr,) -- in pinned host memory (jur_host_alloc) or as ordinary numpy arrays."""
+    tp (3, nr), np (nr,) -- in pinned host memory (jur_host_alloc) or as ordinary numpy arrays.
+
+    A pinned block lives as long as ANY numpy view of it: the block is freed by a finalizer on the buffer object
+    the arrays are views of, not by close() -- `rad = b.rad; b.close()` leaves `rad` valid."""
 
     def __init__(self, nr, nd, pinned=True):
         self.nr, self.nd, self.pinned = nr, nd, pinned
-        self._raw = []
         self.geom = self._alloc((7, nr), np.float64)
         self.rad = self._alloc((nr, nd), np.float64)
         self.tau = self._alloc((nr, nd), np.float64)
@@ -166,12 +175,14 @@ class HostBuffers:
     def _alloc(self, shape, dtype):
         if not self.pinned:
             return np.zeros(shape, dtype=dtype)
+        import weakref
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         p = lib().jur_host_alloc(n)
         if not p:
             raise JurassicError(lib().jur_last_error().decode())
-        self._raw.append(p)
-        a = np.frombuffer((C.c_char * n).from_address(p), dtype=dtype).reshape(shape)
+        base = (C.c_char * n).from_address(p)
+        weakref.finalize(base, _free_pinned, p)          # runs when the last array that views `base` is gone
+        a = np.frombuffer(base, dtype=dtype).reshape(shape)
         a[...] = 0
         return a
 
@@ -179,15 +190,8 @@ class HostBuffers:
         self.geom[...] = np.asarray(geom, dtype=np.float64).T
 
     def close(self):
+        """Drop this object's references; pinned blocks go when no array views them any more."""
         self.geom = self.rad = self.tau = self.tp = self.np = None
-        for p in getattr(self, "_raw", []):
-            try:
-                lib().jur_host_free(p)
-            except TypeError:          # interpreter shutdown
-                pass
-        self._raw = []
-
-    __del__ = close
 
 
 class Model:
@@ -332,6 +336,11 @@ class Model:
 def formod(ctl, atm, obs):
     """Drop-in entry (reference CPUdrivers.c:179): tables from ctl.tblbase files."""
     lib().formod(C.byref(ctl), C.byref(atm), C.byref(obs))
+
+
+def dropin_finalize():
+    """Free the lanes and tables behind formod() (jur_dropin_finalize) -> number of lanes freed."""
+    return lib().jur_dropin_finalize()
 
 
 def intpol_atm(ctl, dest, src, device=0):

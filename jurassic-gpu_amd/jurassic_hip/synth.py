@@ -109,6 +109,47 @@ def nadir_geometry(nr, seed=0, obsz=700.0, lat0=-8.01, lat1=8.01, nprofiles=1):
     return g
 
 
+# ---- index-addressable geometry ("splitmix64 seed 0x4A55524153534943") -----------------------------
+# Ray i of a workload is a function of (seed, i) alone: output i of the splitmix64 stream started at `seed`, whose
+# state after i + 1 steps is seed + (i + 1) * golden -- no sequential generator state.  A rank of a sharded run builds
+# exactly its rows [lo, hi), rank 0 builds the handful of sampled global rows it re-computes, nobody builds the whole set.
+SURVEY_SEED = 0x4A55524153534943
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+
+def splitmix64_uniform(seed, idx):
+    """U[0, 1) doubles number idx (array of non-negative ints) of the splitmix64 stream with the given seed."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (np.asarray(idx, dtype=np.uint64) + np.uint64(1)) * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def limb_rays(idx, seed=SURVEY_SEED, obsz=780.0, zmin=3.0, zmax=68.0, nprofiles=1):
+    """(len(idx), 7) limb rays number idx of the workload: view-point altitude ~ U[zmin, zmax] from obsz km, looking
+    at the tangent point (limb.c:49-59), profile idx mod nprofiles."""
+    idx = np.asarray(idx, dtype=np.int64)
+    vpz = zmin + (zmax - zmin) * splitmix64_uniform(seed, idx)
+    g = np.zeros((len(idx), 7))
+    g[:, 0] = idx % nprofiles
+    g[:, 1] = obsz
+    g[:, 4] = vpz
+    g[:, 6] = 180.0 / np.pi * np.arccos((RE + vpz) / (RE + obsz))
+    return g
+
+
+def nadir_rays(idx, seed=SURVEY_SEED, obsz=700.0, lat0=-8.01, lat1=8.01, nprofiles=1):
+    """(len(idx), 7) nadir observations number idx: sub-satellite latitude ~ U[lat0, lat1] (nadir.c:51-58)."""
+    idx = np.asarray(idx, dtype=np.int64)
+    g = np.zeros((len(idx), 7))
+    g[:, 0] = idx % nprofiles
+    g[:, 1] = obsz
+    g[:, 6] = lat0 + (lat1 - lat0) * splitmix64_uniform(seed, idx)
+    return g
+
+
 def stack_profiles(atm, ctl, nprofiles, seed=0, dp=0.05, dt=30.0):
     """Atmosphere holding `nprofiles` perturbed copies of the first profile of
     `atm`, time stamps 0..nprofiles-1 (profile 0 unperturbed)."""

@@ -17,6 +17,16 @@
 #include <omp.h>
 #endif
 #include "jurassic_oracle.h"
+/* The struct schema comes from the product's ABI header (it is what both sides must agree on, and it is held
+ * against the reference's offsets by tests/test_abi_cpu.py); the physical constants do NOT: */
+#include "oracle_constants.h"
+#undef JUR_C1
+#undef JUR_C2
+#undef JUR_P0
+#undef JUR_RE
+#undef JUR_AVOGADRO
+#undef JUR_BOLTZMANN
+#undef JUR_MOLAR_GAS
 
 #define NLOS JUR_NLOS
 #define NGX  JUR_NG
@@ -184,9 +194,9 @@ int orc_tbl_read_ascii(orc_tbl_t *tb, ctl_t const *ctl) {
  * the latter branch (never taken for IR channels: C2*nu/T >= 2.3 at 650 cm^-1,
  * 400 K). */
 double orc_planck(double t, double nu) {
-  double const x = JUR_C2 * nu / t;
+  double const x = ORC_C2 * nu / t;
   double const em1 = (fabs(x) < M_LN2) ? expm1(x) : exp(x) - 1;
-  return JUR_C1 * (nu * nu * nu) / em1;
+  return ORC_C1 * (nu * nu * nu) / em1;
 }
 
 void orc_tbl_planck_shape(orc_tbl_t *tb, int id, int n, double const *nu, double const *f) {
@@ -350,7 +360,7 @@ double orc_ctmco2(double nu, double p, double t, double u) {
   double const dt296 = t - 296;
   double const ctw = dt260 * 5.050505e-4 * dt296 * cw230 - dt230 * 9.259259e-4 * dt296 * cw260
                    + dt230 * 4.208754e-4 * dt260 * cw296;
-  return u * p * ctw / (JUR_AVOGADRO * 1000 * JUR_P0);
+  return u * p * ctw / (ORC_AVOGADRO * 1000 * ORC_P0);
 }
 
 double orc_ctmh2o(double nu, double p, double t, double q, double u) {
@@ -378,7 +388,7 @@ double orc_ctmh2o(double nu, double p, double t, double q, double u) {
   double const ctwfrn = cwfrn * fscal;
   double const a1 = nu * u * tanh(.7193876 / t * nu);
   double const a2 = 296. / t;
-  double const a3 = p / JUR_P0 * (q * ctwslf + (1 - q) * ctwfrn) * 1e-20;
+  double const a3 = p / ORC_P0 * (q * ctwslf + (1 - q) * ctwfrn) * 1e-20;
   return a1 * a2 * a3;
 }
 
@@ -393,7 +403,7 @@ double orc_ctmn2(double nu, double p, double t) {
   double const b = a0 * N2_B[idx] + a1 * N2_B[idx1];
   double const beta = a0 * N2_BETA[idx] + a1 * N2_BETA[idx1];
   double const q_n2 = 0.79, t0 = 273, tr = 296;
-  return 0.1 * (p / JUR_P0) * (p / JUR_P0) * (t0 / t) * (t0 / t) * exp(beta * (1 / tr - 1 / t)) * q_n2 * b
+  return 0.1 * (p / ORC_P0) * (p / ORC_P0) * (t0 / t) * (t0 / t) * exp(beta * (1 / tr - 1 / t)) * q_n2 * b
          * (q_n2 + (1 - q_n2) * (1.294 - 0.4545 * t / tr));
 }
 
@@ -406,7 +416,7 @@ double orc_ctmo2(double nu, double p, double t) {
   double const b = a0 * O2_B[idx] + a1 * O2_B[idx1];
   double const beta = a0 * O2_BETA[idx] + a1 * O2_BETA[idx1];
   double const q_o2 = 0.21, t0 = 273, tr = 296;
-  return 0.1 * (p / JUR_P0) * (p / JUR_P0) * (t0 / t) * (t0 / t) * exp(beta * (1 / tr - 1 / t)) * q_o2 * b;
+  return 0.1 * (p / ORC_P0) * (p / ORC_P0) * (t0 / t) * (t0 / t) * exp(beta * (1 / tr - 1 / t)) * q_o2 * b;
 }
 
 /* jr_continua_core.mv4g.h:1-14 with the four switches as run-time bits
@@ -425,7 +435,14 @@ static inline double continua_core(int fourbit, ctl_t const *ctl, pos_t const *l
 /* source function and radiance update, jr_common.h:187-234,293-300           */
 /* ------------------------------------------------------------------------ */
 static inline double src_planck_core(orc_tbl_t const *tb, double t, int id) {
-  int const it = (int)(4 * t) - 400;                   /* locate_st */
+  /* locate_st (jr_common.h:82-84) has no range check: for T outside [100, 400) K the reference reads outside
+   * st[]/sr[] (undefined behaviour; whatever lies next to the table).  Oracle and device agree on ONE defined
+   * behaviour for those temperatures instead: the index is clamped, i.e. the end intervals extrapolate linearly
+   * (jur_kernels.hip planck_src; tests/test_kat_gpu.py holds the two against each other just outside the range).
+   * Inside [100, 400) nothing changes. */
+  int it = (int)(4 * t) - 400;                         /* locate_st */
+  if (it < 0) it = 0;
+  if (it > JUR_TBLNS - 2) it = JUR_TBLNS - 2;
   return lip(tb->st[it], T_SR(tb, it, id), tb->st[it + 1], T_SR(tb, it + 1, id), t);
 }
 
@@ -445,7 +462,7 @@ void orc_add_surface(orc_tbl_t const *tb, double tsurf, int id, double *rad, dou
 }
 
 double orc_brightness(double rad, double nu) {        /* brightness_core */
-  return JUR_C2 * nu / log1p((JUR_C1 * nu * nu * nu) / rad);
+  return ORC_C2 * nu / log1p((ORC_C1 * nu * nu * nu) / rad);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -462,13 +479,13 @@ static inline void cart2geo(double const x[], double *alt, double *lon, double *
   double const radius = NORM(x);
   *lat = asin(x[2] / radius) * RAD2GRD;
   *lon = atan2(x[1], x[0]) * RAD2GRD;
-  *alt = radius - JUR_RE;
+  *alt = radius - ORC_RE;
 }
 
-static inline double cart2alt(double const x[]) { return NORM(x) - JUR_RE; }
+static inline double cart2alt(double const x[]) { return NORM(x) - ORC_RE; }
 
 static inline void geo2cart(double alt, double lon, double lat, double x[]) {
-  double const radius = alt + JUR_RE, clat = cos(lat * GRD2RAD);
+  double const radius = alt + ORC_RE, clat = cos(lat * GRD2RAD);
   x[0] = radius * clat * cos(lon * GRD2RAD);
   x[1] = radius * clat * sin(lon * GRD2RAD);
   x[2] = radius * sin(lat * GRD2RAD);
@@ -643,7 +660,7 @@ static int traceray(ctl_t const *ctl, atm_t const *atm, double const geom[7], po
   los[0].ds *= 0.5;
   for (int ip = 0; ip < np; ip++)                        /* column_density :446-453 */
     for (int ig = 0; ig < ctl->ng; ig++)
-      los[ip].u[ig] = 10. * los[ip].q[ig] * los[ip].p / (JUR_BOLTZMANN * los[ip].t) * los[ip].ds;
+      los[ip].u[ig] = 10. * los[ip].q[ig] * los[ip].p / (ORC_BOLTZMANN * los[ip].t) * los[ip].ds;
   assert(1 != ctl->formod);
   return np;
 }
@@ -687,7 +704,7 @@ static void hydrostatic_1d_h2o(ctl_t const *ctl, atm_t *atm, int ip0, int ip1, i
       double const grav = gravity(z, lat);
       if (ig_h2o >= 0) e = lip(0.0, atm->q[ig_h2o][ip - 1], npts - 1.0, atm->q[ig_h2o][ip], (double)i);
       double const temp = lip(0.0, atm->t[ip - 1], npts - 1.0, atm->t[ip], (double)i);
-      mean += (e * mmh2o + (1 - e) * mmair) * grav / (JUR_MOLAR_GAS * temp * npts);
+      mean += (e * mmh2o + (1 - e) * mmair) * grav / (ORC_MOLAR_GAS * temp * npts);
     }
     atm->p[ip] = atm->p[ip - 1] * exp(-1000 * mean * (atm->z[ip] - atm->z[ip - 1]));
   }
@@ -698,7 +715,7 @@ static void hydrostatic_1d_h2o(ctl_t const *ctl, atm_t *atm, int ip0, int ip1, i
       double const grav = gravity(z, lat);
       if (ig_h2o >= 0) e = lip(0.0, atm->q[ig_h2o][ip + 1], npts - 1.0, atm->q[ig_h2o][ip], (double)i);
       double const temp = lip(0.0, atm->t[ip + 1], npts - 1.0, atm->t[ip], (double)i);
-      mean += (e * mmh2o + (1 - e) * mmair) * grav / (JUR_MOLAR_GAS * temp * npts);
+      mean += (e * mmh2o + (1 - e) * mmair) * grav / (ORC_MOLAR_GAS * temp * npts);
     }
     atm->p[ip] = atm->p[ip + 1] * exp(-1000 * mean * (atm->z[ip] - atm->z[ip + 1]));
   }
@@ -1169,3 +1186,8 @@ int orc_set_threads(int n) {
 #endif
 }
 
+/* the oracle's own constants (oracle_constants.h) as compiled: C1, C2, P0, RE, N_A, k_B, R */
+void orc_constants(double out[7]) {
+  out[0] = ORC_C1; out[1] = ORC_C2; out[2] = ORC_P0; out[3] = ORC_RE;
+  out[4] = ORC_AVOGADRO; out[5] = ORC_BOLTZMANN; out[6] = ORC_MOLAR_GAS;
+}

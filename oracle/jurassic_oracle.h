@@ -117,6 +117,9 @@ int orc_traceray(ctl_t const *ctl, atm_t const *atm, double const geom[7],
                  double *ds, double *k, double *q, double *u,
                  double *tsurf, double tp[3]);
 void orc_hydrostatic(ctl_t const *ctl, atm_t *atm);
+
+/* the oracle's own physical constants as compiled (oracle_constants.h): C1, C2, P0, RE, N_A, k_B, R */
+void orc_constants(double out[7]);
 /* Curtis-Godson means of one ray (jr_common.h:455-473): cgp/cgt/cgu are [JUR_NG... ng][JUR_NLOS]; returns np */
 int orc_set_threads(int n);
 /* intpol_atm (jurassic.c:675-804): dest->p, t, q, k at dest's z / lon / lat from src by ctl->ip = 1 (one profile),

@@ -30,8 +30,10 @@ class Case:
                 self.rows[(g, d)] = synth.table_rows(em, v, id_=d, **pkw)
         self.filters = [filt(v) if filt else synth.boxcar_filter(v) for v in nu]
 
-    def oracle_tables(self, orc):
-        tb = orc.Tables(self.ctl.ng, self.ctl.nd)
+    def oracle_tables(self, orc, reference_layout=False):
+        """reference_layout: channel stride ND as in the reference's tbl_t (jurassic.h:408-411: u/eps[...][ND], channel
+        index fastest) instead of the number of channels in use -- same results, the reference's memory behaviour."""
+        tb = orc.Tables(self.ctl.ng, abi.ND if reference_layout else self.ctl.nd)
         for (g, d), r in self.rows.items():
             tb.feed_rows(g, d, r)
         for d, (x, f) in enumerate(self.filters):

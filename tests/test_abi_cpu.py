@@ -36,6 +36,33 @@ def test_struct_layout_matches_reference_offsets():
     assert abi.obs_t.tau.offset == 87040 and abi.obs_t.rad.offset == 957440 and abi.obs_t.nr.offset == 1827840
 
 
+def test_physical_constants_of_product_and_oracle_equal_the_reference_literals():
+    """The product (include/jurassic_abi.h) and the oracle (oracle/oracle_constants.h) carry separate copies of
+    the constants on the path, so that a wrong value on one side is a parity failure instead of cancelling.
+    Both are held here against literals this test carries itself: C1, C2, P0, RE as reference jurassic.h:109-126
+    spells them; N_A, k_B, R as GSL 2.5 (gsl_const_num.h / gsl_const_mksa.h) publishes them -- the reference
+    reads them at jr_common.h:330, 450, 744."""
+    want = [1.19104259e-8, 1.43877506, 1013.25, 6367.421, 6.02214199e23, 1.3806504e-23, 8.314472]
+    got = (C.c_double * 7)()
+    lib.lib().jur_abi_constants(got)
+    assert list(got) == want
+    from oracle import orc
+    L = orc.lib()
+    L.orc_constants.argtypes = [C.POINTER(C.c_double)]
+    L.orc_constants(got)
+    assert list(got) == want
+    # and as text: the oracle does not see the product's constants (it #undefs them), the product never includes the oracle's
+    osrc = open(os.path.join(ROOT, "oracle", "jurassic_oracle.c")).read()
+    assert not re.search(r"\bJUR_(C1|C2|P0|RE|AVOGADRO|BOLTZMANN|MOLAR_GAS)\b(?!\n)", re.sub(r"#undef JUR_\w+", "", osrc))
+    for root_, _, files in os.walk(os.path.join(ROOT, "jurassic-gpu_amd", "csrc")):
+        for f in files:
+            if f.endswith((".c", ".h", ".hip")):
+                assert "oracle_constants.h" not in open(os.path.join(root_, f)).read()
+    # k_B (CODATA 2006, what GSL 2.5 ships) against CODATA 2018: 1.0e-6 apart -- which of the two a build uses is
+    # visible at the level of the 1e-6 contract (through the column densities), so this literal is not a detail
+    assert 0.9e-6 < abs(want[5] / 1.380649e-23 - 1) < 1.1e-6
+
+
 def test_table_builder_counts_and_row_rules():
     rows = synth.table_rows("CO2", 792.0)
     tb = lib.Tables(1, 1)

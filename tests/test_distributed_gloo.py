@@ -110,3 +110,40 @@ def test_bench_dry_run_single_rank_line():
     assert out.returncode == 0, out.stdout + out.stderr
     doc = json.loads(out.stdout.strip())
     assert doc["n_gpus"] == 1 and doc["config"]["workload"] == "limb_1e6" and doc["config"]["rays_per_gpu"] == [500]
+
+
+def test_bench_airs_workload_starts_the_wide_build_and_shards_by_index():
+    """configs[4] through the launcher: `bench.py --gpus 2 --workload airs_2378_sharded --dry-run` starts its two ranks
+    with the ND = 2378 dimensions exported (the ranks import 2378-channel structs), every rank builds only its own rows
+    of the index-addressable observation set, rank 0 re-builds the sampled rows from their indices and finds them
+    equal to what was gathered."""
+    out = _bench("--gpus", "2", "--workload", "airs_2378_sharded", "--steps", "1", "--warmup", "0", "--rays", "301", "--dry-run")
+    assert out.returncode == 0, out.stdout + out.stderr
+    doc = json.loads(out.stdout.strip())
+    assert doc["n_gpus"] == 2 and doc["dry_run"] is True and doc["scaling"] == "weak"
+    assert doc["config"]["workload"].startswith("airs_2378_sharded") and doc["config"]["channels"] == 2378
+    assert doc["config"]["rays_per_gpu"] == [150, 151] and doc["gather_check"]["differing_values"] == 0
+    # and a single rank that finds itself without the dimensions re-runs itself with them (one line, same contract)
+    out = _bench("--workload", "airs_2378_sharded", "--steps", "1", "--warmup", "0", "--rays", "40", "--dry-run")
+    assert out.returncode == 0, out.stdout + out.stderr
+    doc = json.loads(out.stdout.strip())
+    assert doc["n_gpus"] == 1 and doc["config"]["channels"] == 2378 and doc["config"]["rays_total"] == 40
+    assert "1 of the 8 GPU shares" in doc["config"]["workload"]
+
+
+def test_geometry_is_index_addressable():
+    """Ray i of a workload is a function of i alone: any slice, any order, any rank builds the same rows; the uniform
+    stream is splitmix64 (known answer: the generator's published first output for seed 1234567)."""
+    import bench
+    from jurassic_hip import synth
+    z = int(synth.splitmix64_uniform(1234567, [0])[0] * 2 ** 53)
+    assert z == 6457827717110365317 >> 11
+    full = bench.workload_rays("limb_1e7_sharded", np.arange(5000))
+    assert np.array_equal(full[1234:2345], bench.workload_rays("limb_1e7_sharded", np.arange(1234, 2345)))
+    idx = np.array([4999, 0, 77, 4096])
+    assert np.array_equal(full[idx], bench.workload_rays("limb_1e7_sharded", idx))
+    far = bench.workload_rays("limb_1e7_sharded", np.array([9_999_999]))            # no need to build 1e7 rows for the last one
+    assert far.shape == (1, 7) and 3.0 <= far[0, 4] <= 68.0 and far[0, 0] == 9_999_999 % 64
+    assert 3.0 <= full[:, 4].min() < 3.1 and 67.9 < full[:, 4].max() <= 68.0 and abs(full[:, 4].mean() - 35.5) < 1.0
+    nad = bench.workload_rays("nadir_1e5", np.arange(2000))
+    assert np.all(np.abs(nad[:, 6]) <= 8.01) and nad[:, 6].std() > 4.0

@@ -11,7 +11,11 @@ end-to-end parity tests only reach by chance:
   add_surface_core / brightness_core      jr_common.h:187-190, 227-234
 
 The look-up is plain IEEE arithmetic in the reference's operand order, so ega_eps must come back BIT-IDENTICAL in
-every mode; functions that call exp / tanh / pow / log1p are held to a few ulp of the device math library.
+modes 0 .. 2 (the reference's bisections; warm-started searches, descriptors from global memory / from LDS): these
+are the known-answer reference on the device.  Mode 3 -- what the kernels run on strictly increasing tables since
+round 3 -- replaces the reference's divisions by cheaper ones that are NOT correctly rounded (jur_kernels.hip,
+div_fast / lip_mulr) and is held to the same oracle within FAST_ABS on the path transmittance, a factor 1e6 inside
+the 1e-6 contract.  Functions that call exp / tanh / pow / log1p are held to a few ulp of the device math library.
 """
 import os
 import numpy as np
@@ -37,6 +41,20 @@ def bits(a):
 def same_doubles(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return np.array_equal(bits(a)[~np.isnan(a)], bits(b)[~np.isnan(b)]) and np.array_equal(np.isnan(a), np.isnan(b))
+
+
+FAST_ABS = 2e-13     # mode 3 against the oracle: |(1 - eps_t)_device - (1 - eps_t)_oracle|, both in [0, 1]
+
+
+def fast_close(got, ref, tau):
+    """ega_eps returns (1 - eps_t) / tau; mode 3 forms 1 - eps_t with divisions good to ~2^-46 of an interpolation
+    increment.  Compared where the reference is finite, as the path transmittance it stands for."""
+    got, ref, tau = (np.asarray(x, dtype=np.float64) for x in (got, ref, tau))
+    fin = np.isfinite(ref)
+    if not np.array_equal(fin, np.isfinite(got)):
+        return False, np.inf
+    err = np.abs((got[fin] - ref[fin]) * tau[fin])
+    return bool(np.all(err <= FAST_ABS)), float(err.max()) if err.size else 0.0
 
 
 def around(x, k=2):
@@ -79,22 +97,30 @@ def test_ega_eps_at_gates_and_axis_ends_is_bit_identical_in_every_mode(hip, orac
         tau, t, u, p = ega_inputs(case.rows[(ig, id_)], seed=10 * ig + id_)
         ref = oracle.ega_eps(ot, ig, id_, tau, t, u, p)
         assert np.all(ref[tau < 1e-9] == 0.0) and np.any(tau < 1e-9) and np.any(ref[tau >= 1e-9] > 0)     # the gate itself
-        for mode in (0, 1, 2, 3):
+        for mode in (0, 1, 2):
             got = m.kat_ega_eps(ig, id_, tau, t, u, p, mode=mode)
             bad = np.nonzero(bits(got) != bits(ref))[0]
             assert len(bad) == 0, (mode, ig, id_, len(bad), tau[bad[:3]], t[bad[:3]], u[bad[:3]], p[bad[:3]], got[bad[:3]], ref[bad[:3]])
+        got3 = m.kat_ega_eps(ig, id_, tau, t, u, p, mode=3)
+        ok, worst = fast_close(got3, ref, tau)
+        print("mode 3 vs oracle, pair (%d, %d): worst |d(1 - eps_t)| = %.2e over %d inputs" % (ig, id_, worst, len(tau)))
+        assert ok, (ig, id_, worst)
+        assert np.array_equal(got3[tau < 1e-9], ref[tau < 1e-9])            # the gate answers 0 exactly in every mode
         # the searches resume from wherever the previous look-up ended: the result must not depend on that
         k = 4000
-        for mode in (1, 2, 3):
+        for mode in (1, 2):
             got = m.kat_ega_eps(ig, id_, tau[:k], t[:k], u[:k], p[:k], mode=mode, chain=True)
             assert same_doubles(got, ref[:k]), (mode, ig, id_)
+        got = m.kat_ega_eps(ig, id_, tau[:k], t[:k], u[:k], p[:k], mode=3, chain=True)
+        assert same_doubles(got, got3[:k]), ("mode 3: chained == unchained, bit for bit", ig, id_)
     # NaN inputs come back as the reference's comparisons hand them through
     tau = np.array([0.5, np.nan, 0.5, 0.5, 0.5]); t = np.array([250.0, 250.0, np.nan, 250.0, 250.0])
     u = np.array([1e18, 1e18, 1e18, np.nan, 1e18]); p = np.array([100.0, 100.0, 100.0, 100.0, np.nan])
     ref = oracle.ega_eps(ot, 0, 0, tau, t, u, p)
     for mode in (0, 1, 2, 3):
         got = m.kat_ega_eps(0, 0, tau, t, u, p, mode=mode)
-        assert np.array_equal(np.isnan(got), np.isnan(ref)) and got[0] == ref[0], (mode, got, ref)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), (mode, got, ref)
+        assert got[0] == ref[0] if mode < 3 else abs(got[0] - ref[0]) * tau[0] <= FAST_ABS, (mode, got, ref)
     m.close()
 
 
@@ -109,8 +135,11 @@ def test_ega_eps_other_table_shapes(hip, oracle, kw, modes):
     tau, t, u, p = ega_inputs(case.rows[(1, 1)], seed=3, n_random=3000)
     ref = oracle.ega_eps(ot, 1, 1, tau, t, u, p)
     for mode in range(4):
-        if mode in modes:
+        if mode in modes and mode < 3:
             assert same_doubles(m.kat_ega_eps(1, 1, tau, t, u, p, mode=mode), ref), mode
+        elif mode in modes:
+            ok, worst = fast_close(m.kat_ega_eps(1, 1, tau, t, u, p, mode=3), ref, tau)
+            assert ok, (mode, worst)
         else:
             with pytest.raises(hip.JurassicError):
                 m.kat_ega_eps(1, 1, tau, t, u, p, mode=mode)
@@ -161,7 +190,11 @@ def test_source_function_update_gate_surface_and_brightness(hip, oracle):
     rng = np.random.default_rng(2)
     gate = around(1e-50, 3) + [0.0, 1e-60, 1e-49, 1e-300, 1.0, 0.3]
     n = 3000
-    t = np.concatenate([[100.0, 100.25, 399.99, 399.75, 250.0, 250.125], rng.uniform(100.0, 399.99, n - 6)])
+    # the table covers [100, 400) K; the reference's locate_st reads out of range beyond (jr_common.h:82-84): oracle
+    # and device both clamp the index (end intervals extrapolate) -- held against each other just outside and far outside
+    edge = [100.0, 100.25, 399.99, 399.75, 250.0, 250.125, np.nextafter(100.0, 0), 99.9, 50.0, 0.0, -10.0,
+            400.0, np.nextafter(400.0, 500), 400.1, 450.0, 1000.0]
+    t = np.concatenate([edge, rng.uniform(100.0, 399.99, n - len(edge))])
     tau_gas = np.concatenate([gate, 10.0 ** rng.uniform(-60, 0, n - len(gate))])
     beta = np.concatenate([[0.0, 700.0, 1e-300], 10.0 ** rng.uniform(-12, 2, n - 3)])
     rad0, tau0 = rng.uniform(0, 1e-3, n), rng.uniform(0, 1, n)
@@ -173,7 +206,7 @@ def test_source_function_update_gate_surface_and_brightness(hip, oracle):
         assert np.any(closed) and np.array_equal(rad[closed], rad0[closed]) and np.array_equal(tau[closed], tau0[closed])
         assert np.array_equal(rrad[closed], rad0[closed]) and np.array_equal(rtau[closed], tau0[closed])
         # exp of the device library differs from libm's in the last place: eps = 1 - tau_gas exp(-beta) moves by ~1e-16
-        assert np.all(np.abs(rad - rrad) <= 4e-16 * (np.abs(rrad) + rsrc))
+        assert np.all(np.abs(rad - rrad) <= 4e-16 * (np.abs(rrad) + np.abs(rsrc)))
         assert np.abs(tau - rtau).max() <= 4e-16
         # epilogue: surface term for tsurf > 0 (-999 = no ground hit), brightness temperature where asked
         tsurf = np.where(rng.uniform(size=n) < 0.5, t, -999.0)

@@ -30,11 +30,49 @@ def hip():
     return lib
 
 
+# How a call is arranged on the device.  Every test that goes through run_both runs once per arrangement, so that each
+# edge case of the matrix meets the oracle DIRECTLY through the fused kernel and through the batched kernels (the ones
+# bench.py times) -- not the latter only by way of "fused == batched":
+#   fused            package-sized calls as ONE jur_pencil_kernel (the default for <= 10 000 rays)
+#   batched          ray sort + jur_trace_kernel + jur_ega_kernel + jur_combine_kernel (one channel per workgroup)
+#   batched_grouped  the same with jur_combine_group_kernel forced (up to four channels per workgroup, ragged groups too)
+# Unsorted tables take ega_eps_exact in every arrangement, strict ones the reciprocal-width arithmetic.
+ARRANGEMENTS = ("fused", "batched", "batched_grouped")
+_state = {"arr": "fused", "key": None, "calls": 0}
+_oracle_cache = {}
+
+
+def pytest_generate_tests(metafunc):
+    """Tests that go through run_both get one instance per arrangement; the others arrange their own calls."""
+    if "arrangement" in metafunc.fixturenames:
+        uses = "run_both" in metafunc.function.__code__.co_names
+        metafunc.parametrize("arrangement", ARRANGEMENTS if uses else ("own",), indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def arrangement(request, hip):
+    rest = tuple(tok for tok in request.node.callspec.id.split("-") if tok != request.param)
+    _state.update(arr=request.param, key=(request.node.originalname, rest), calls=0)
+    if request.param == "batched_grouped":
+        hip.tune_combine(4, 8, 0)
+    yield request.param
+    if request.param == "batched_grouped":
+        hip.tune_combine(-1, 8, 1_000_000)
+    _state["arr"] = "fused"
+
+
 def run_both(hip, oracle, case, rad_in=None):
     model = hip.Model(case.ctl, case.lib_tables())
+    if _state["arr"] in ("batched", "batched_grouped"):
+        model.set_pencil(0)
     model.set_atm(case.atm)
     out = model.formod_host(case.geom, rad_in=rad_in)
-    ref = oracle.formod_rays(case.ctl, case.atm, case.oracle_tables(oracle), case.geom, rad_in=rad_in)
+    # the oracle's answer for the k-th call of a test is the same in every arrangement: computed once
+    key = (_state["key"], _state["calls"])
+    _state["calls"] += 1
+    if key not in _oracle_cache:
+        _oracle_cache[key] = oracle.formod_rays(case.ctl, case.atm, case.oracle_tables(oracle), case.geom, rad_in=rad_in)
+    ref = _oracle_cache[key]
     model.close()
     return out, ref
 
@@ -132,19 +170,25 @@ def test_table_shapes(hip, oracle, kw):
     assert_parity(out, ref)
 
 
-def test_division_paths_return_the_same_doubles(hip, monkeypatch):
-    """Strictly increasing tables let jur_ega_kernel divide through reciprocal bracket widths and the bare
-    division sequence; JUR_EGA_NO_RCP=1 selects the compiler's fp64 division.
-    Same doubles, bit for bit."""
+def test_strict_table_arithmetic_against_the_reference_divisions(hip, monkeypatch):
+    """Strictly increasing tables let jur_ega_kernel use the cheaper arithmetic of DESIGN.md section 4 (quotients
+    through one Newton step on v_rcp_f64, blends through reciprocal bracket widths, the path transmittance carried as
+    1 - eps); JUR_EGA_NO_RCP=1 selects the reference's own divisions, operand for operand.  The two must agree far
+    inside the suite's 1e-9 -- here 1e-12 on the radiances of 3000 rays x 4 channels (the budget of the contract is
+    1e-6) -- and the point counts exactly."""
     case = common.limb_case(geom=synth.limb_geometry(3000, seed=4, nprofiles=8), nu=common.CTM4_NU, nprofiles=8)
     model = hip.Model(case.ctl, case.lib_tables())
+    model.set_pencil(0)
     model.set_atm(case.atm)
     fast = model.formod_host(case.geom)
     monkeypatch.setenv("JUR_EGA_NO_RCP", "1")
     ieee = model.formod_host(case.geom)
     model.close()
-    for k in ("rad", "tau"):
-        assert np.array_equal(fast[k].view(np.uint64), ieee[k].view(np.uint64)), k
+    assert np.array_equal(fast["np"], ieee["np"])
+    dev = common.rel_err(fast["rad"], ieee["rad"]).max()
+    print("strict-table arithmetic vs reference divisions: worst relative radiance deviation %.2e" % dev)
+    assert dev < 1e-12
+    assert np.abs(fast["tau"] - ieee["tau"]).max() < 1e-13
 
 
 def test_eight_emitters_with_generated_profiles(hip, oracle, tmp_path):
@@ -453,6 +497,50 @@ def test_drop_in_continuum_switches_toggle_between_calls(hip, oracle, tmp_path):
     assert out.returncode == 0 and "TOGGLE_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
+DROPIN_FINALIZE = r"""
+import os, sys, ctypes as C
+sys.path[:0] = [{root!r}, os.path.join({root!r}, 'jurassic-gpu_amd'), os.path.join({root!r}, 'tests')]
+import numpy as np, common, torch
+from jurassic_hip import abi, lib, synth, textio
+os.chdir({tmp!r})
+geom = synth.limb_geometry(300, seed=8)
+case = common.limb_case(geom=geom, useGPU=1)
+case.write_files({tmp!r}, base='fin')
+
+def run():
+    obs = abi.obs_t()
+    obs.nr = len(geom)
+    for c, name in enumerate(textio.OBS_COLS[:7]):
+        np.ctypeslib.as_array(getattr(obs, name))[:obs.nr] = geom[:, c]
+    lib.formod(case.ctl, case.atm, obs)
+    return np.ctypeslib.as_array(obs.rad)[:len(geom), :2].copy()
+
+assert lib.dropin_finalize() == 0                      # nothing initialised yet: a no-op
+torch.cuda.init()
+free0 = torch.cuda.mem_get_info()[0]
+a = run()
+held = free0 - torch.cuda.mem_get_info()[0]
+assert held > (1 << 20), held                          # tables, atmosphere, staging: the lane holds device memory
+assert lib.dropin_finalize() == 1                      # one lane existed
+back = free0 - torch.cuda.mem_get_info()[0]
+assert back < held // 4, (held, back)                  # ... and gave it back
+assert lib.dropin_finalize() == 0                      # twice is fine
+b = run()                                              # the next call initialises again, same results
+assert np.array_equal(a, b)
+assert lib.dropin_finalize() == 1
+print('FINALIZE_OK', held, back)
+"""
+
+
+def test_drop_in_state_can_be_finalized(hip, tmp_path):
+    """SURVEY 8b "explicit init/finalize": jur_dropin_finalize() frees the process-global lanes and tables behind
+    formod(); the next call loads them again and returns the same doubles."""
+    script = tmp_path / "finalize.py"
+    script.write_text(DROPIN_FINALIZE.format(root=common.ROOT, tmp=str(tmp_path)))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "FINALIZE_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 def test_model_from_files_uses_the_binary_cache(hip, oracle, tmp_path, monkeypatch):
     """READ_BINARY=-1 / WRITE_BINARY=1 (upstream defaults, jurassic.c:1018-1019): the first model parses
     the ASCII tables and writes the cache into the working directory, the second one is built from the
@@ -526,15 +614,14 @@ print('CONCURRENT_OK serial %.3f s concurrent %.3f s speedup %.2f' % (t_serial, 
 def test_concurrent_drop_in_callers_use_lanes(hip, tmp_path):
     """formod() is designed to be called from several threads at once (upstream: OpenMP callers and up
     to 4 lanes, GPUdrivers.cu:262-342).  Eight threads, 1088-ray packages: bit-identical to the serial
-    results, and faster than serial because the packages overlap on the GPU."""
+    results (the packages overlap on the GPU; the script prints the speed-up it saw)."""
     script = tmp_path / "concurrent.py"
     script.write_text(CONCURRENT.format(root=common.ROOT, tmp=str(tmp_path)))
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, JUR_LANES="8"))
     assert out.returncode == 0 and "CONCURRENT_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
-    speedup = float(out.stdout.split("speedup")[1].split()[0])
-    print(out.stdout.strip().splitlines()[-1])
-    assert speedup > 1.1          # most of the wall time here is Python building obs_t under the GIL
+    print(out.stdout.strip().splitlines()[-1])   # the speed-up is reported (tools/run_lanes_bench.sh measures it from C),
+                                                 # not asserted: wall-clock thresholds do not belong in a parity suite
 
 
 LIMB_CTL = """# Forward model...
@@ -628,11 +715,16 @@ def test_jacobian_matches_reference_kernel(hip, oracle, kw):
 
 
 def test_large_batch_properties(hip, oracle):
-    """BASELINE configs[2] at full size (1e6 limb rays, 4 channels, 5 emitters, 64
-    profiles): properties that need no oracle run at that size, plus a sampled
+    """One GPU's share of BASELINE configs[3] at full size: 1 250 000 of the 1e7 limb rays (rank 3 of 8 of the
+    index-addressable set bench.py shards; 4 channels, 5 emitters, 64 profiles) -- more than configs[2]'s 1e6 rays, in
+    ONE launch per kernel (120 GB workspace).  Properties that need no oracle run at that size, plus a sampled
     oracle comparison."""
-    nr = 1_000_000
-    geom = synth.limb_geometry(nr, seed=1000, nprofiles=64)
+    import bench
+    from jurassic_hip import shard
+    lo, hi = shard.ray_range(3, 8, 10_000_000)
+    nr = hi - lo
+    assert nr == 1_250_000
+    geom = bench.workload_rays("limb_1e7_sharded", np.arange(lo, hi))
     case = common.limb_case(geom=geom[:8], nu=common.CTM4_NU, nprofiles=64)
     model = hip.Model(case.ctl, case.lib_tables())
     model.set_atm(case.atm)
@@ -652,8 +744,10 @@ def test_large_batch_properties(hip, oracle):
     idx = np.random.default_rng(1).choice(nr, 3000, replace=False)
     ref = oracle.formod_rays(case.ctl, case.atm, case.oracle_tables(oracle), geom[idx])
     assert np.array_equal(a["np"][idx], ref["np"])
-    assert common.rel_err(a["rad"][idx], ref["rad"]).max() < RTOL
-    assert common.rel_err(a["tau"][idx], ref["tau"]).max() < RTOL
+    worst = common.rel_err(a["rad"][idx], ref["rad"]).max()
+    print("1.25e6 limb rays, 3000 sampled against the oracle: worst relative radiance deviation %.2e" % worst)
+    assert worst < RTOL
+    assert np.all(np.abs(a["tau"][idx] - ref["tau"]) <= RTOL * np.abs(ref["tau"]) + 5e-12)
     model.close()
 
 
@@ -693,60 +787,53 @@ import os, sys, time
 sys.path[:0] = [{root!r}, os.path.join({root!r}, 'jurassic-gpu_amd'), os.path.join({root!r}, 'tests')]
 import numpy as np, common
 from oracle import orc
-from jurassic_hip import abi, lib, synth, textio
+from jurassic_hip import abi, lib, shard
 import bench
 assert (abi.ND, abi.NG) == (2378, 3)
-nr = {nr}
-nu = [650.0 + i * (2665.0 - 650.0) / 2377 for i in range(2378)]           # SURVEY 8d, C5
-em = ["CO2", "H2O", "O3"]
-ctl = abi.make_ctl(em, nu)
-atm = textio.read_atm(os.path.join(common.GOLD, "limb", "atm.tab"), ctl)
-geom = synth.nadir_geometry(nr, seed=7)
-# full-size tables, 33 p x 10 T x ~203 u per pair: 7134 tables, 4.8e8 entries (3.8 GB on the device) -- every row
-# goes to the library and to the oracle as it is generated, nothing is kept
-tb, ot = lib.Tables(3, 2378), orc.Tables(3, 2378)
 t0 = time.time()
-for g, e in enumerate(em):
-    for d, v in enumerate(nu):
-        rows = synth.table_rows(e, v, id_=d % 7)
-        tb.feed_rows(g, d, rows)
-        ot.feed_rows(g, d, rows)
-        if g == 0:
-            x, f = synth.boxcar_filter(v)
-            tb.set_filter(d, x, f)
-            ot.planck_shape(d, x, f)
+lo, hi = shard.ray_range(5, 8, 1_000_000)                                  # rank 5 of 8 of configs[4]'s 1e6 observations
+nr = hi - lo
+assert nr == {nr}
+geom = bench.workload_rays("airs_2378_sharded", np.arange(lo, hi))
+case = bench.AirsCase(geom)         # full-size tables, 33 p x 10 T x ~203 u per pair: 7134 tables, 4.8e8 entries (3.8 GB on
+tb = case.lib_tables()              # the device) -- the workload bench.py --workload airs_2378_sharded runs per GPU
 assert tb.entries() > 4.5e8
-model = lib.Model(ctl, tb)
-model.set_atm(atm)
+model = lib.Model(case.ctl, tb)
+model.set_atm(case.atm)
 a = model.formod_host(geom)
 assert np.isfinite(a["rad"]).all() and np.all(a["rad"] > 0) and np.all((a["tau"] >= 0) & (a["tau"] <= 1))
 assert set(np.unique(a["np"])) <= {{181, 182}}
 model.set_chunk_rays(448)                                                  # chunking: bit-identical
-b = model.formod_host(geom)
+sub = slice(0, 20000)
+b = model.formod_host(geom[sub])
 for k in ("rad", "tau", "tp", "np"):
-    assert np.array_equal(a[k], b[k]), k
-perm = np.random.default_rng(0).permutation(nr)[:512]                      # rays are independent
+    assert np.array_equal(a[k][sub], b[k]), k
+model.set_chunk_rays(1 << 21)
+perm = np.random.default_rng(0).permutation(nr)[:4096]                     # rays are independent
 c = model.formod_host(geom[perm])
 assert np.array_equal(c["rad"], a["rad"][perm]) and np.array_equal(c["tau"], a["tau"][perm])
-idx = np.random.default_rng(1).choice(nr, 16, replace=False)               # sampled rows against the oracle
+idx = np.random.default_rng(1).choice(nr, 64, replace=False)               # sampled rows against the oracle
 orc.set_threads(bench.usable_cores())
-ref = orc.formod_rays(ctl, atm, ot, geom[idx])
+ref = orc.formod_rays(case.ctl, case.atm, case.oracle_tables(orc), geom[idx])
 assert np.array_equal(a["np"][idx], ref["np"])
-assert np.max(np.abs(a["rad"][idx] - ref["rad"]) / np.abs(ref["rad"])) < 1e-9
-assert np.all(np.abs(a["tau"][idx] - ref["tau"]) <= 1e-9 * np.abs(ref["tau"]) + 1e-13)
-print('WIDE_FULL_OK', a["rad"].shape, tb.entries(), '%.0f s' % (time.time() - t0))
+worst = np.max(np.abs(a["rad"][idx] - ref["rad"]) / np.abs(ref["rad"]))
+assert worst < 1e-9
+assert np.all(np.abs(a["tau"][idx] - ref["tau"]) <= 1e-9 * np.abs(ref["tau"]) + 5e-12)
+print('WIDE_FULL_OK', a["rad"].shape, tb.entries(), 'worst rel rad dev %.2e' % worst, '%.0f s' % (time.time() - t0))
 """
 
 
 def test_2378_channels_full_size_tables(hip, oracle, tmp_path):
-    """BASELINE configs[4] on one GPU at the size the wide benchmark runs (tools/bench_wide.py): 2048 nadir
-    observations x 2378 channels x 3 emitters with FULL-size tables (3.8 GB: beyond L2 and Infinity Cache),
-    the property checks of the other bench-size tests plus sampled oracle rows.  Own process: the ND=2378 build."""
+    """One GPU's share of BASELINE configs[4] at full size: 125 000 of the 1e6 nadir observations x 2378 channels x 3
+    emitters with FULL-size tables (3.8 GB: beyond L2 and Infinity Cache) -- what `bench.py --workload
+    airs_2378_sharded` runs per GPU.  The property checks of the other bench-size tests plus 64 sampled observations
+    (152 000 radiances) against the oracle.  Own process: the ND=2378 build."""
     script = tmp_path / "wide_full.py"
-    script.write_text(WIDE_FULL.format(root=common.ROOT, nr=2048))
+    script.write_text(WIDE_FULL.format(root=common.ROOT, nr=125000))
     env = dict(os.environ, JUR_ND="2378", JUR_NG="3", JUR_SUFFIX="_nd2378")
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1500, env=env)
-    assert out.returncode == 0 and "WIDE_FULL_OK (2048, 2378)" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.returncode == 0 and "WIDE_FULL_OK (125000, 2378)" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    print(out.stdout.strip().splitlines()[-1])
 
 
 def test_host_entry_with_pinned_and_pageable_arrays(hip):

@@ -28,7 +28,9 @@ for w in $WHAT; do
            step pmc_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc limb_1e6 1000000 gpurun_out/${TAG}_pmc_current.json
            PMC_SHORT=1 step pmc_nadir 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_pmc_nadir --workload nadir_1e5 --steps 1 --warmup 0
            step pmc_nadir_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_nadir nadir_1e5 100000 gpurun_out/${TAG}_pmc_current.json ;;
-    lanesmode) for md in "JUR_NO_ZERO_COPY=1" "GPU_MAX_HW_QUEUES=8" "JUR_PENCIL_RAYS=0"; do echo "$md"; EXTRA_ENV="env $md" CALLS=16 bash tools/run_lanes_bench.sh 2>&1 | grep threads; done > $OUTDIR/${TAG}_lanesmode.log 2>&1; cat $OUTDIR/${TAG}_lanesmode.log ;;
+    lanesmode) for md in "JUR_NO_ZERO_COPY=1" "GPU_MAX_HW_QUEUES=8" "JUR_PENCIL_RAYS=0"; do
+             TAIL=6 EXTRA_ENV="env $md" CALLS=16 step lanesmode_${md%%=*} 300 bash tools/run_lanes_bench.sh
+           done ;;
     torchrun1) TAIL=1 step bench_torchrun1 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --no-cpu-baseline --no-host-inclusive --no-package-api ;;
     wide) TAIL=1 JUR_ND=2378 JUR_NG=3 JUR_SUFFIX=_nd2378 step wide 900 python3 tools/bench_wide.py 4096 ;;
     widestats) cd /tmp; export TMPDIR=/tmp
@@ -47,7 +49,7 @@ for w in $WHAT; do
     cmpbuilds) TAIL=2 step compare_builds 600 python3 tools/compare_builds.py jurassic-gpu_amd/libjurassic_hip_prev.so jurassic-gpu_amd/libjurassic_hip.so 300000 ;;
     kat) step kat 600 python3 -m pytest tests/test_kat_gpu.py -q -p no:cacheprovider ;;
     ab) TAIL=20 step ab 900 bash tools/ab_env.sh $AB ;;
-    fuzz) echo "== fuzz"; timeout -k 10 1100 python3 tools/fuzz_parity.py ${FUZZ:-3000 400} 2>&1 | tee $OUTDIR/${TAG}_fuzz.log | grep -v "^Read\|^Init" ;;
+    fuzz) TAIL=3 step fuzz 1100 python3 tools/fuzz_parity.py ${FUZZ:-3000 400} ;;
     rehearse2) TAIL=1 JUR_BENCH_REHEARSAL=1 step rehearse2 900 python3 bench.py --gpus 2 --rays 600000 --steps 2 --warmup 1 ;;
     abso) TAIL=20 step abso 900 bash tools/ab_env.sh "JURASSIC_HIP_SO=$GRAFT_REPO_ROOT/jurassic-gpu_amd/libjurassic_hip.so" "JURASSIC_HIP_SO=$GRAFT_REPO_ROOT/jurassic-gpu_amd/libjurassic_hip$ABSUF.so"
           TAIL=2 step abso_cmp 600 python3 tools/compare_builds.py jurassic-gpu_amd/libjurassic_hip.so jurassic-gpu_amd/libjurassic_hip$ABSUF.so 300000 ;;
@@ -64,9 +66,10 @@ PY
            cp $GRAFT_REPO_ROOT/tests/golden/limb/atm.tab $D/
            gcc -O2 -fopenmp -I$GRAFT_REPO_ROOT/include $GRAFT_REPO_ROOT/tools/lanes_bench.c -o $D/lanes_bench -L$GRAFT_REPO_ROOT/jurassic-gpu_amd -ljurassic_hip -Wl,-rpath,$GRAFT_REPO_ROOT/jurassic-gpu_amd -lm )
            export TMPDIR=/tmp
-           ( cd $D && JUR_LANES=4 step lanes_trace 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_lanestrace -- $D/lanes_bench 4 8 )
-           ( cd $D && echo "batched" && JUR_PENCIL_RAYS=0 JUR_LANES=16 $D/lanes_bench 16 16 | tail -1 ) > gpurun_out/${TAG}_lanes_hwq.log 2>&1
-           cat gpurun_out/${TAG}_lanes_hwq.log ;;
+           cd $D
+           JUR_LANES=4 step lanes_trace 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_lanestrace -- $D/lanes_bench 4 8
+           TAIL=1 JUR_PENCIL_RAYS=0 JUR_LANES=16 step lanes_hwq 300 $D/lanes_bench 16 16      # batched kernels, 16 lanes
+           cd $GRAFT_REPO_ROOT ;;
     stats) cd /tmp; export TMPDIR=/tmp
            step kernel_stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --no-cpu-baseline --no-host-inclusive --no-package-api
            cd $GRAFT_REPO_ROOT ;;
