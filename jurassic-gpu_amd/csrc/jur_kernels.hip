@@ -106,7 +106,7 @@ __device__ __forceinline__ double lip_finite(double x0, double y0, double x1, do
 //   radiance update divides the products over the gases of consecutive segments instead: one division per
 //   (channel, segment) in place of one per (channel, gas, segment)).
 // tests/test_kat_gpu.py holds this path against the bit-exact ones (modes 0 .. 2), which stay the known-answer
-// reference against the oracle.
+// reference on the device.
 __device__ __forceinline__ double div_fast(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
   r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
