@@ -15,7 +15,9 @@ typedef struct { float u, eps; } jur_ue_t;
 /* 16-byte descriptors: one load brings the axis value together with the extent
  * and the offset of the next level of the hierarchy. */
 typedef struct { double p; int nt; int c0; } jur_lvl_t;   /* pressure level: nt curves from curve c0 */
-typedef struct { double t; int nu; int e0; } jur_crv_t;   /* curve: nu (u,eps) entries from entry e0 */
+typedef struct { double t; int nu; int e0; } jur_crv_t;   /* curve: nu (u,eps) entries from entry e0 OF ITS PAIR
+                                                             (pair_e0[pair] + e0 in the ue array): 32 bits hold any
+                                                             pair (<= 40 x 30 x 304 entries), the set may hold > 2^31 */
 
 /* Everything about the continua that depends on the channel only, reduced on
  * the host once per model with the reference's own expression order
@@ -52,6 +54,9 @@ typedef struct {
   jur_lvl_t const *lvl;
   jur_crv_t const *crv;
   jur_ue_t const *ue;
+  long long const *pair_e0;     /* [ng*nd] first entry of every pair in ue (64 bits: a full-extent many-channel set --
+                                   2378 channels x 3 gases x 40 x 30 x 304 = 2.6e9 entries -- is addressed as
+                                   wave-uniform pair base + 32-bit offset inside the pair)                        */
   int sorted_tables;            /* every axis and curve is non-decreasing: any bracket search
                                    finds what the reference's bisection finds                  */
   int atm_maxslice;             /* longest run of equal time stamps in the atmosphere          */
@@ -155,6 +160,7 @@ typedef struct {
   int strict;                   /* ... strictly increasing, curves as stored     */
   int max_pair_curves;
   jur_int2 *pair;
+  long long *pair_e0;           /* [npair] first entry of the pair in ue */
   jur_lvl_t *lvl;
   jur_crv_t *crv;
   jur_ue_t *ue;

@@ -119,6 +119,50 @@ __device__ __forceinline__ double lip_mulr(double x0, double y0, double y1, doub
   return y0 + ((x - x0) * (y1 - y0)) * r;
 }
 
+// exp(x) of the radiance update and the continua (round 3).  The device library's exp is a degree-11 polynomial whose
+// eleven coefficients the compiler keeps in 22 VGPRs across the segment loop and copies in front of every Horner
+// step (v_mov_b64 + v_fmac_f64): ~35 vector instructions per call, three to four calls per (segment, channel).  This
+// one reduces x = (64 m + j) ln2/64 + r, |r| <= ln2/128, takes 2^(j/64) from a 64-entry table (correctly rounded
+// doubles; in LDS in the batched kernels) and needs a degree-5 polynomial in r (remainder r^6/720 < 4e-17):
+// 17 vector instructions and one table read, within ~1 ulp of the library's result -- 1e-16 relative where the
+// contract is 1e-6.  |x| is clamped to 1000 (beyond +-745 the result is 0 or inf either way), NaN goes through.
+__device__ const double JUR_EXP2_64[64] = {
+  1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+  1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+  1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
+  1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+  1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
+  1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
+  1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
+  1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+  1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+  1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+  1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
+  1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
+  1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
+  1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+  1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+  1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951};
+
+template <class Tab>
+__device__ __forceinline__ double exp_tab(Tab const &tab, double x) {
+  double const xc = __builtin_fmin(__builtin_fmax(x, -1000.), 1000.);
+  double const k = __builtin_rint(xc * 92.33248261689366);              // 64 / ln 2
+  int const n = (int)k;
+  double r = __builtin_fma(k, -0.01083042468962958, xc);                // ln2/64, upper bits (trailing zeros: exact)
+  r = __builtin_fma(k, -6.619564634077006e-12, r);                      // ... and the rest
+  double q = __builtin_fma(r, 1. / 120, 1. / 24);
+  q = __builtin_fma(q, r, 1. / 6);
+  q = __builtin_fma(q, r, 0.5);
+  q = __builtin_fma(q * r, r, r);                                       // e^r - 1
+  double const t = tab[n & 63];
+  double const res = __builtin_ldexp(__builtin_fma(t, q, t), n >> 6);
+  return (x != x) ? x : res;
+}
+// the table where a kernel has no copy in LDS
+struct Exp2Global { __device__ __forceinline__ double operator[](int j) const { return JUR_EXP2_64[j]; } };
+struct Exp2Lds { double const *t; __device__ __forceinline__ double operator[](int j) const { return t[j]; } };
+
 // bracket search on an ascending or descending axis (jr_common.h:87-104)
 __device__ __forceinline__ int locate_axis(double const *__restrict__ xx, int n, double x) {
   int ilo = 0, ihi = n - 1, i = (n - 1) >> 1;
@@ -180,9 +224,16 @@ __device__ __forceinline__ int locate_axis_from(double const *__restrict__ xx, i
 // WANT_R: the caller interpolates more quantities on the same bracket; for a sorted axis (dir != 0: z strictly
 // monotone, bracket width non-zero) it gets rdz = RN(1 / (zb - za)) and every such interpolation, the
 // temperature's included, divides through it (lip_rcp: the same doubles, 3 instructions per quotient).
-template <bool WANT_R = false>
+// the exponential of the pressure interpolation (eip, jr_common.h:53-57): the device library's, or -- JUR_TRACE_EXP_TAB,
+// an A/B switch of the build -- the table form of the radiance update
+#ifdef JUR_TRACE_EXP_TAB
+#define TRACE_EXP(x) exp_tab(e2t, (x))
+#else
+#define TRACE_EXP(x) exp(x)
+#endif
+template <bool WANT_R = false, class Tab = Exp2Global>
 __device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, double z0, double &p, double &t, int dir,
-                                         int &hint, double *rdz = nullptr) {
+                                         int &hint, double *rdz = nullptr, Tab const &e2t = Tab()) {
   int const loc = dir ? locate_axis_from(v.atm_z + i0, n, z0, dir, hint) : locate_axis(v.atm_z + i0, n, z0);
   hint = loc;
   int const ip = i0 + loc;
@@ -193,10 +244,10 @@ __device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, dou
   if (WANT_R && dir) {
     double const r = 1. / (zb - za);
     *rdz = r;
-    p = (sl == sl) ? v.atm_p[ip] * exp(sl * (z0 - za)) : lip_rcp(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0, r);
+    p = (sl == sl) ? v.atm_p[ip] * TRACE_EXP(sl * (z0 - za)) : lip_rcp(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0, r);
     t = lip_rcp(za, v.atm_t[ip], zb, v.atm_t[ip + 1], z0, r);
   } else {
-    p = (sl == sl) ? v.atm_p[ip] * exp(sl * (z0 - za)) : lip(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0);
+    p = (sl == sl) ? v.atm_p[ip] * TRACE_EXP(sl * (z0 - za)) : lip(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0);
     t = lip(za, v.atm_t[ip], zb, v.atm_t[ip + 1], z0);
   }
   return ip;
@@ -405,7 +456,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
       }
 
       double p, t, rdz = 0;
-      int const ia = intpol_pt<true>(v, atm0, atmn, z, p, t, zdir, zhint, &rdz);
+      int const ia = intpol_pt<true>(v, atm0, atmn, z, p, t, zdir, zhint, &rdz, L.e2t());
       double const dsn = (np >= 1) ? 0.5 * (ds_p + ds) : ds * 0.5;   // redone for the point before the exit
       L.at(JUR_F_DS, np) = dsn;
       {  // remaining quantities on the same bracket (jr_common.h:557-567)
@@ -462,7 +513,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
                                 (j == 3) ? xh[2] + h : xh[2]};
           cart2geo(xq, zz, llon, llat);
           double rdzb = 0;
-          intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb);   // (lip_rcp == lip: same doubles as the plain search)
+          intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb, L.e2t());   // (lip_rcp == lip: same doubles as the plain search)
           double const nj = refractivity(pp, tt), n2 = quad_bcast<0>(nj);
           ngr[0] = div_rcp(quad_bcast<1>(nj) - n2, h, 1. / h);
           ngr[1] = div_rcp(quad_bcast<2>(nj) - n2, h, 1. / h);
@@ -470,7 +521,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
         } else {
         cart2geo(xh, zz, llon, llat);
         double rdzb = 0;
-        int const ib = intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb);
+        int const ib = intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb, L.e2t());
         double const n2 = refractivity(pp, tt);
         // the three displaced probes lie 0.02 km away: almost always in the bracket just found, whose six
         // values are then reused instead of being looked up and loaded again
@@ -484,10 +535,11 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
           bool const inside = (zdir > 0) ? ((zz >= za || first) && (zz < zb || lastb))
                             : (zdir < 0) ? ((zz < za || first) && (zz >= zb || lastb)) : false;
           if (inside) {
-            pp = (sl == sl) ? pa * exp(sl * (zz - za)) : lip_rcp(za, pa, zb, pb, zz, rdzb);   // inside => sorted axis
+            auto const e2t = L.e2t();
+            pp = (sl == sl) ? pa * TRACE_EXP(sl * (zz - za)) : lip_rcp(za, pa, zb, pb, zz, rdzb);   // inside => sorted axis
             tt = lip_rcp(za, ta, zb, tb, zz, rdzb);
           } else {
-            intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
+            intpol_pt<false>(v, atm0, atmn, zz, pp, tt, zdir, rhint, nullptr, L.e2t());
           }
           ngr[i] = div_rcp(refractivity(pp, tt) - n2, h, 1. / h);
           xh[i] -= h;
@@ -551,6 +603,8 @@ struct LosWorkspace {
   double *los;
   size_t R;
   int r;
+  double const *e2;            // 2^(j/64) in LDS
+  __device__ __forceinline__ Exp2Lds e2t() const { return Exp2Lds{e2}; }
   __device__ __forceinline__ double &at(int field, int ip) const { return los[((size_t)field * NLOS + ip) * R + r]; }
   __device__ __forceinline__ size_t field_stride() const { return (size_t)NLOS * R; }
   __device__ __forceinline__ void begin_point(int) const {}
@@ -563,10 +617,13 @@ struct LosWorkspace {
 // launch carries enough rays (>= 4 x 131072) to fill them
 __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chunk_t c) {
   __shared__ double tr_sh[15][64];
+  __shared__ double e2_sh[64];
+  e2_sh[threadIdx.x & 63] = JUR_EXP2_64[threadIdx.x & 63];
+  __syncthreads();
   int const r = blockIdx.x * blockDim.x + threadIdx.x;   // slot in the chunk
   if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
-  LosWorkspace L{c.los, (size_t)c.stride, r};
+  LosWorkspace L{c.los, (size_t)c.stride, r, e2_sh};
   TraceResult const t = trace_ray(v, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray], c.geom[4][ray],
                                   c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
   c.np[r] = t.np;
@@ -598,7 +655,9 @@ static_assert(sizeof(Lvl) == sizeof(jur_lvl_t) && sizeof(Crv) == sizeof(jur_crv_
 
 // Table element access as (wave-uniform base pointer) + (32-bit byte offset): the address is
 // formed by the memory instruction itself (SGPR base + VGPR offset) instead of 64-bit vector
-// arithmetic per load.  Offsets fit 32 bits: the host refuses tables beyond 2^29 entries.
+// arithmetic per load.  Descriptors count from their array's base (the host refuses sets beyond 2^27 levels or
+// curves); table entries count from the first entry of their (gas, channel) pair (PairDesc::ueb, a 64-bit base that
+// is uniform wherever a workgroup works on one pair), so a set may hold any number of entries.
 template <class T>
 __device__ __forceinline__ T ldg(void const *__restrict__ base, unsigned index) {
   return *reinterpret_cast<T const *>(static_cast<char const *>(base) + (size_t)(index * (unsigned)sizeof(T)));
@@ -745,6 +804,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char jur_lds[];
 template <bool LDS>
 struct PairDesc {
   void const *lvb, *cvb;       // global arrays
+  void const *ueb;             // first (u, eps) entry of the pair
   unsigned l0;                 // first level of the pair
   unsigned kbase;              // first curve of the pair (LDS copy starts there)
   __device__ __forceinline__ Lvl lvl(int i) const {
@@ -775,7 +835,7 @@ __device__ __forceinline__ double ega_eps_exact(jur_view_t const &v, jur_int2 co
                                                 double u, double p) {
   if (tau < 1e-9) return 0.;
   if (pr.a < 2) return 1.;
-  void const *const ueb = v.ue;
+  void const *const ueb = D.ueb;
   int ilo = 0, ihi = pr.a - 1;
   while (ihi > ilo + 1) {  // ascending-only bisection, whatever the axis looks like
     int const i = (ihi + ilo) >> 1;
@@ -840,7 +900,7 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
   double const one = PATH ? tau : 1.;          // the look-up's "no change" answer
   if (tau < 1e-9) return 0.;
   if (pr.a < 2) return one;
-  void const *const ueb = v.ue;
+  void const *const ueb = D.ueb;
   int ipr = min((int)(br & 0xffu), pr.a - 2);
   Lvl l0 = D.lvl(ipr), l1 = D.lvl(ipr + 1);
   if ((p < l0.p) | (p >= l1.p)) {
@@ -943,7 +1003,7 @@ __device__ __forceinline__ double ega_eps_warm_quad(jur_view_t const &v, jur_int
   double const one = FAST ? tau : 1.;
   if (tau < 1e-9) return 0.;
   if (pr.a < 2) return one;
-  void const *const ueb = v.ue;
+  void const *const ueb = D.ueb;
   int ipr = min((int)(br & 0xffu), pr.a - 2);
   Lvl l0 = D.lvl(ipr), l1 = D.lvl(ipr + 1);
   if ((p < l0.p) | (p >= l1.p)) {
@@ -1019,10 +1079,11 @@ __device__ __forceinline__ double ctm_co2(jur_chan_t const &ch, double p, double
 // ratio^y for a per-channel constant ratio: exp(y ln ratio) with ln ratio = hi + lo prepared on the host
 // (64-bit logarithm) and the product y ln ratio carried with its rounding error -- about 1 ulp like the
 // library's pow, which spends most of its ~180 instructions on that logarithm.
-__device__ __forceinline__ double pow_const(double lnr_hi, double lnr_lo, double y) {
+template <class Tab>
+__device__ __forceinline__ double pow_const(Tab const &tab, double lnr_hi, double lnr_lo, double y) {
   double const ph = y * lnr_hi;
   double const pl = __builtin_fma(y, lnr_hi, -ph) + y * lnr_lo;
-  double const e = exp(ph);
+  double const e = exp_tab(tab, ph);
   return __builtin_fma(e, pl, e);
 }
 
@@ -1037,36 +1098,41 @@ __device__ __forceinline__ double rcp_t(double t) {
   return __builtin_fma(r, __builtin_fma(-t, r, 1.0), r);
 }
 
-// tanh(x) for the x = 0.7193876 nu / T of the H2O continuum (jr_common.h:354): (1 - e) / (1 + e) with
-// e = exp(-2x) -- one exp and one division instead of the library's tanh (which branches on the size of x and
-// costs about twice as much).  1 - e loses log2(1 / 2x) bits to cancellation: used for nu >= 100 cm^-1, where
-// x >= 0.07 for any T <= 1000 K (relative error <= 2e-15); channels below that take the library function.
-__device__ __forceinline__ double tanh_pos(double x) {
-  double const e = exp(-2. * x);
+// tanh(x) for the x = 0.7193876 nu / T > 0 of the H2O continuum (jr_common.h:354): (1 - e) / (1 + e) with
+// e = exp(-2x) -- one exp and one division instead of the library's tanh (which branches on the size of x, costs about
+// twice as much and keeps a second set of polynomial coefficients in registers across the segment loop).  1 - e loses
+// log2(1 / 2x) bits to cancellation: relative error ~1e-16 / 2x, i.e. <= 2e-15 for nu >= 100 cm^-1 at any T <= 1000 K
+// and 2e-14 for a channel at 1 cm^-1 -- eight orders inside the contract.
+template <class Tab>
+__device__ __forceinline__ double tanh_pos(Tab const &tab, double x) {
+  double const e = exp_tab(tab, -2. * x);
   return div_finite(1. - e, 1. + e);
 }
 
-__device__ __forceinline__ double ctm_h2o(jur_chan_t const &ch, double p, double t, double rt, double q, double u) {
+template <class Tab>
+__device__ __forceinline__ double ctm_h2o(Tab const &tab, jur_chan_t const &ch, double p, double t, double rt, double q, double u) {
   double const y = div_const<T36_DEN>(296. - t);
-  double const ctwslf = ch.h2o_sc * pow_const(ch.h2o_lnr_hi, ch.h2o_lnr_lo, y);
+  double const ctwslf = ch.h2o_sc * pow_const(tab, ch.h2o_lnr_hi, ch.h2o_lnr_lo, y);
   double const x = .7193876 * rt * ch.nu;
-  double const a1 = ch.nu * u * ((ch.nu >= 100.) ? tanh_pos(x) : tanh(x));
+  double const a1 = ch.nu * u * tanh_pos(tab, x);
   double const a2 = 296. * rt;
   double const a3 = div_const<P0_DEN>(p) * (q * ctwslf + (1 - q) * ch.h2o_ctwfrn) * 1e-20;
   return a1 * a2 * a3;
 }
 
-__device__ __forceinline__ double ctm_n2(jur_chan_t const &ch, double p, double t, double rt) {
+template <class Tab>
+__device__ __forceinline__ double ctm_n2(Tab const &tab, jur_chan_t const &ch, double p, double t, double rt) {
   double const q_n2 = 0.79, t0 = 273, tr = 296;
   double const pr = div_const<P0_DEN>(p), s = t0 * rt;
-  return 0.1 * pr * pr * s * s * exp(ch.n2_beta * (1 / tr - rt)) * q_n2 * ch.n2_b
+  return 0.1 * pr * pr * s * s * exp_tab(tab, ch.n2_beta * (1 / tr - rt)) * q_n2 * ch.n2_b
          * (q_n2 + (1 - q_n2) * (1.294 - div_const<TR_DEN>(0.4545 * t)));
 }
 
-__device__ __forceinline__ double ctm_o2(jur_chan_t const &ch, double p, double t, double rt) {
+template <class Tab>
+__device__ __forceinline__ double ctm_o2(Tab const &tab, jur_chan_t const &ch, double p, double t, double rt) {
   double const q_o2 = 0.21, t0 = 273, tr = 296;
   double const pr = div_const<P0_DEN>(p), s = t0 * rt;
-  return 0.1 * pr * pr * s * s * exp(ch.o2_beta * (1 / tr - rt)) * q_o2 * ch.o2_b;
+  return 0.1 * pr * pr * s * s * exp_tab(tab, ch.o2_beta * (1 / tr - rt)) * q_o2 * ch.o2_b;
 }
 
 __device__ __forceinline__ double planck_src(double const *__restrict__ sr, double t) {
@@ -1090,9 +1156,10 @@ __device__ __forceinline__ double segment_tau_gas(double pcur, double pprev) {
 }
 
 // radiance update of one segment (new_obs_core, jr_common.h:293-300)
-__device__ __forceinline__ void new_obs_step(double tau_gas, double beta_ds, double src, double &rad, double &tau) {
+template <class Tab>
+__device__ __forceinline__ void new_obs_step(Tab const &tab, double tau_gas, double beta_ds, double src, double &rad, double &tau) {
   if (tau_gas > 1e-50) {
-    double const eps = 1. - tau_gas * exp(-beta_ds);
+    double const eps = 1. - tau_gas * exp_tab(tab, -beta_ds);
     rad += src * eps * tau;
     tau *= (1. - eps);
   }
@@ -1156,7 +1223,7 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   int const pair_idx = g * v.nd + d;
   jur_int2 const pd = v.pair[pair_idx];
   if (pd.a < 2) return;                          // no table: transmittance 1, the combine kernel knows
-  PairDesc<LDS> D{v.lvl, v.crv, (unsigned)pd.b, 0u, 0u, 0u};
+  PairDesc<LDS> D{v.lvl, v.crv, v.ue + v.pair_e0[pair_idx], (unsigned)pd.b, 0u, 0u, 0u};
   stage_pair<LDS, RCPB>(v, pd, D);
   if (r >= c.n) return;
   size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
@@ -1205,9 +1272,11 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
   // the channel's source-function table (1201 doubles) is staged in LDS: its two reads per segment are
   // gathers by temperature, everything else this kernel loads is a coalesced stream
   double *const sr = reinterpret_cast<double *>(jur_lds);
+  Exp2Lds const e2t{sr + TBLNS};                       // 2^(j/64), 64 doubles behind the source-function table
   {
     double const *const gsr = v.sr + (size_t)d * TBLNS;
     for (int i = threadIdx.x; i < TBLNS; i += blockDim.x) sr[i] = gsr[i];
+    if (threadIdx.x < 64) sr[TBLNS + threadIdx.x] = JUR_EXP2_64[threadIdx.x];
     __syncthreads();
   }
   if (r >= c.n) return;
@@ -1233,15 +1302,15 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
     double beta_ds = L(f_k) * ds;
     if (do_co2) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
     double const rt = rcp_t(t);
-    if (do_h2o) beta_ds += ctm_h2o(ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
-    if (do_n2) beta_ds += ctm_n2(ch, p, t, rt) * ds;
-    if (do_o2) beta_ds += ctm_o2(ch, p, t, rt) * ds;
+    if (do_h2o) beta_ds += ctm_h2o(e2t, ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
+    if (do_n2) beta_ds += ctm_n2(e2t, ch, p, t, rt) * ds;
+    if (do_o2) beta_ds += ctm_o2(e2t, ch, p, t, rt) * ds;
     double pcur = 1.0;
     for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
       if ((has_table >> g) & 1u) pcur *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
     double const tau_gas = segment_tau_gas(pcur, pprev);
     pprev = pcur;
-    new_obs_step(tau_gas, beta_ds, planck_src(sr, t), rad, tau);
+    new_obs_step(e2t, tau_gas, beta_ds, planck_src(sr, t), rad, tau);
   }
   ray_epilogue(sr, ch.nu, c.tsurf[r], v.write_bbt, rad, tau);
   if (masked) rad = __builtin_nan("");
@@ -1256,7 +1325,10 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
 // (FETCH_SIZE of the kernel -29 %).  The kernel waits on its dependent chains more than on HBM, so this is worth
 // 4 % of its time, not 29 (17.3 against 18.1 ms per 1e6 limb rays); one channel per workgroup remains for nd = 1.
 // The wave index is made uniform (readfirstlane) so that the channel constants stay in scalar registers.
-__global__ __launch_bounds__(512, 6) void jur_combine_group_kernel(jur_view_t v, jur_chunk_t c, int nsb, int CG, int SYNC) {   // SYNC: mask, see the loop
+#ifndef JUR_COMBINE_WAVES
+#define JUR_COMBINE_WAVES 6
+#endif
+__global__ __launch_bounds__(512, JUR_COMBINE_WAVES) void jur_combine_group_kernel(jur_view_t v, jur_chunk_t c, int nsb, int CG, int SYNC) {   // SYNC: mask, see the loop
   int const nd = v.nd, ng = v.ng;
   int const ncg = (nd + CG - 1) / CG, SUB = (int)(blockDim.x >> 6) / CG;
   int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
@@ -1268,7 +1340,9 @@ __global__ __launch_bounds__(512, 6) void jur_combine_group_kernel(jur_view_t v,
   bool const live_wave = d < nd;
   double *const sr = reinterpret_cast<double *>(jur_lds) + (size_t)cw * TBLNS;
   int *const npmax_sh = reinterpret_cast<int *>(reinterpret_cast<double *>(jur_lds) + (size_t)CG * TBLNS);
+  Exp2Lds const e2t{reinterpret_cast<double *>(jur_lds) + (size_t)CG * TBLNS + 2};   // 2^(j/64), 64 doubles
   if (threadIdx.x == 0) *npmax_sh = 0;
+  if (threadIdx.x < 64) reinterpret_cast<double *>(jur_lds)[(size_t)CG * TBLNS + 2 + threadIdx.x] = JUR_EXP2_64[threadIdx.x];
   for (int k = 0; k < CG; k++) {
     if (cg * CG + k >= nd) break;
     double const *const gsr = v.sr + (size_t)(cg * CG + k) * TBLNS;
@@ -1305,15 +1379,15 @@ __global__ __launch_bounds__(512, 6) void jur_combine_group_kernel(jur_view_t v,
       double beta_ds = L(f_k) * ds;
       if (do_co2) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
       double const rt = rcp_t(t);
-      if (do_h2o) beta_ds += ctm_h2o(ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
-      if (do_n2) beta_ds += ctm_n2(ch, p, t, rt) * ds;
-      if (do_o2) beta_ds += ctm_o2(ch, p, t, rt) * ds;
+      if (do_h2o) beta_ds += ctm_h2o(e2t, ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
+      if (do_n2) beta_ds += ctm_n2(e2t, ch, p, t, rt) * ds;
+      if (do_o2) beta_ds += ctm_o2(e2t, ch, p, t, rt) * ds;
       double pcur = 1.0;
       for (int g = 0; g < ng; g++)
         if ((has_table >> g) & 1u) pcur *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
       double const tau_gas = segment_tau_gas(pcur, pprev);
       pprev = pcur;
-      new_obs_step(tau_gas, beta_ds, planck_src(sr, t), rad, tau);
+      new_obs_step(e2t, tau_gas, beta_ds, planck_src(sr, t), rad, tau);
     }
     if ((ip & SYNC) == SYNC) __syncthreads();      // SYNC = 2^k - 1 (0: a barrier after every segment; -1 never matches: none)
   }
@@ -1382,6 +1456,7 @@ __device__ __forceinline__ bool first_active_lane() {
 
 // LOS fields of the workgroup's rays in the LDS ring [point % PEN_RING][field][ray]
 struct LosRing {
+  __device__ __forceinline__ Exp2Global e2t() const { return Exp2Global(); }
   double *ring;
   PenCtl *ctl;
   int *npr;
@@ -1554,7 +1629,7 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
     // chain, one corner curve each ----
     constexpr int CS = (QUAD && WARM) ? 2 : 0;                  // lanes per chain = 1 << CS
     int const w = wave - 1, nl = (NE * 64) >> CS, me = (w * 64 + lane) >> CS;
-    PairDesc<false> D{v.lvl, v.crv, 0u, 0u, 0u, 0u};
+    PairDesc<false> D{v.lvl, v.crv, nullptr, 0u, 0u, 0u, 0u};
     for (int ip = 0;; ++ip) {
       int const cnt = wait_point(&ctl, ip);
       if (cnt <= ip) break;
@@ -1569,6 +1644,7 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
         jur_int2 const pd = v.pair[g * nd + d];
         if (pd.a < 2) continue;                                    // no table: the combine role knows
         D.l0 = (unsigned)pd.b;
+        D.ueb = v.ue + v.pair_e0[g * nd + d];
         double const p = slot[JUR_F_P * RB + r], t = slot[JUR_F_T * RB + r], u = slot[(JUR_F_K + v.nw + g) * RB + r];
         double const tau_path = st_tau[e];
         double tau_new;                                            // the gas's path transmittance after this segment
@@ -1592,6 +1668,7 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
     // ---- combine: one lane per (ray, channel) ----
     int const w = wave - 1 - NE, nl = NC * 64, me = w * 64 + lane;
     int const f_u = JUR_F_K + v.nw;
+    Exp2Global const e2t;
     for (int ip = 0;; ++ip) {
       int const cnt = wait_point(&ctl, ip);
       if (cnt <= ip) break;
@@ -1608,16 +1685,16 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
         double beta_ds = L(JUR_F_K + ch.window) * ds;
         if ((v.fourbit & 8) && ch.co2_on) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
         double const rt = rcp_t(t);
-        if ((v.fourbit & 4) && ch.h2o_on) beta_ds += ctm_h2o(ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
-        if ((v.fourbit & 2) && ch.n2_on) beta_ds += ctm_n2(ch, p, t, rt) * ds;
-        if ((v.fourbit & 1) && ch.o2_on) beta_ds += ctm_o2(ch, p, t, rt) * ds;
+        if ((v.fourbit & 4) && ch.h2o_on) beta_ds += ctm_h2o(e2t, ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
+        if ((v.fourbit & 2) && ch.n2_on) beta_ds += ctm_n2(e2t, ch, p, t, rt) * ds;
+        if ((v.fourbit & 1) && ch.o2_on) beta_ds += ctm_o2(e2t, ch, p, t, rt) * ds;
         double pcur = 1.0;
         for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
           if (v.pair[g * nd + d].a >= 2) pcur *= eslot[(d * ng + g) * RB + r];
         double const tau_gas = segment_tau_gas(pcur, c_pp[i]);
         c_pp[i] = pcur;
         double rad = c_rad[i], tau = c_tau[i];
-        new_obs_step(tau_gas, beta_ds, planck_src(v.sr + (size_t)d * TBLNS, t), rad, tau);
+        new_obs_step(e2t, tau_gas, beta_ds, planck_src(v.sr + (size_t)d * TBLNS, t), rad, tau);
         c_rad[i] = rad;
         c_tau[i] = tau;
       }
@@ -1855,7 +1932,7 @@ __global__ __launch_bounds__(256) void jur_kat_ega_kernel(jur_view_t v, int g, i
                                                           double const *__restrict__ t, double const *__restrict__ u,
                                                           double const *__restrict__ p, int chain, double *__restrict__ out) {
   jur_int2 const pd = v.pair[g * v.nd + d];
-  PairDesc<LDS> D{v.lvl, v.crv, (unsigned)pd.b, 0u, 0u, 0u};
+  PairDesc<LDS> D{v.lvl, v.crv, v.ue + v.pair_e0[g * v.nd + d], (unsigned)pd.b, 0u, 0u, 0u};
   if (pd.a >= 2) stage_pair<LDS, RCPB>(v, pd, D);       // uniform branch; stage_pair ends in a barrier
   unsigned br = 0, ia = 0, ib = 0;
   auto one = [&](long i) {
@@ -1881,9 +1958,10 @@ __global__ __launch_bounds__(256) void jur_kat_continua_kernel(jur_view_t v, int
   jur_chan_t const ch = v.chan[d];
   out[i] = ch.co2_on ? ctm_co2(ch, p[i], t[i], u_co2[i]) : 0.;
   double const rt = rcp_t(t[i]);
-  out[n + i] = ch.h2o_on ? ctm_h2o(ch, p[i], t[i], rt, q[i], u_h2o[i]) : 0.;
-  out[2 * n + i] = ch.n2_on ? ctm_n2(ch, p[i], t[i], rt) : 0.;
-  out[3 * n + i] = ch.o2_on ? ctm_o2(ch, p[i], t[i], rt) : 0.;
+  Exp2Global const e2t;
+  out[n + i] = ch.h2o_on ? ctm_h2o(e2t, ch, p[i], t[i], rt, q[i], u_h2o[i]) : 0.;
+  out[2 * n + i] = ch.n2_on ? ctm_n2(e2t, ch, p[i], t[i], rt) : 0.;
+  out[3 * n + i] = ch.o2_on ? ctm_o2(e2t, ch, p[i], t[i], rt) : 0.;
 }
 
 // what == 0: src = source function at t = a[i]; (rad, tau) updated by one segment with tau_gas = b[i], beta_ds = c[i]
@@ -1897,7 +1975,7 @@ __global__ __launch_bounds__(256) void jur_kat_update_kernel(jur_view_t v, int d
   double const *const sr = v.sr + (size_t)d * TBLNS;
   double r = rad[i], tt = tau[i];
   src[i] = planck_src(sr, a[i]);
-  if (what == 0) new_obs_step(b[i], c[i], src[i], r, tt);
+  if (what == 0) new_obs_step(Exp2Global(), b[i], c[i], src[i], r, tt);
   else ray_epilogue(sr, v.chan[d].nu, a[i], b[i] != 0., r, tt);
   rad[i] = r;
   tau[i] = tt;
@@ -1981,11 +2059,11 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
     unsigned const g2 = (unsigned)(((nsb + 7) / 8) * 8 * ncg);
     int mask = -1;                                 // barrier every 2^k segments, k from JUR_COMBINE_SYNC (<= 0: none)
     if (sync > 0) { mask = 1; while (mask * 2 <= sync) mask *= 2; mask -= 1; }
-    hipLaunchKernelGGL(jur_combine_group_kernel, dim3(g2), dim3(64 * W), sizeof(double) * JUR_TBLNS * CG + 16, (hipStream_t)stream,
+    hipLaunchKernelGGL(jur_combine_group_kernel, dim3(g2), dim3(64 * W), sizeof(double) * (JUR_TBLNS * CG + 2 + 64), (hipStream_t)stream,
                        *v, *c, nsb, CG, mask);
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL(jur_combine_kernel, dim3(grid), dim3(block), sizeof(double) * JUR_TBLNS, (hipStream_t)stream, *v, *c,
+  hipLaunchKernelGGL(jur_combine_kernel, dim3(grid), dim3(block), sizeof(double) * (JUR_TBLNS + 64), (hipStream_t)stream, *v, *c,
                      nrb);
   return (int)hipGetLastError();
 }

@@ -32,7 +32,7 @@ struct jur_model {
   jur_view_t view;              /* device pointers                               */
   long table_bytes;
   /* device allocations owned by the model */
-  void *d_chan, *d_sr, *d_pair, *d_lvl, *d_crv, *d_ue;
+  void *d_chan, *d_sr, *d_pair, *d_pair_e0, *d_lvl, *d_crv, *d_ue;
   void *d_atm;                  /* one slab for the compact atmosphere           */
   int atm_cap;
   int atm_slices;               /* distinct time stamps in the atmosphere        */
@@ -184,6 +184,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   if (rc) { jur_model_destroy(m); return rc; }
   long const npair = (long)ctl->ng * ctl->nd;
   rc = upload(&m->d_pair, fl.pair, sizeof(jur_int2) * (npair > 0 ? npair : 1));
+  if (!rc) rc = upload(&m->d_pair_e0, fl.pair_e0, sizeof(long long) * (npair > 0 ? npair : 1));
   if (!rc) rc = upload(&m->d_lvl, fl.lvl, sizeof(jur_lvl_t) * (fl.nlevel + 2));
   if (!rc) rc = upload(&m->d_crv, fl.crv, sizeof(jur_crv_t) * (fl.ncurve + 2));
   if (!rc) rc = upload(&m->d_ue, fl.ue, sizeof(jur_ue_t) * (fl.nentry + 2));
@@ -196,6 +197,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   v->chan = (jur_chan_t const *)m->d_chan;
   v->sr = (double const *)m->d_sr;
   v->pair = (jur_int2 const *)m->d_pair;
+  v->pair_e0 = (long long const *)m->d_pair_e0;
   v->lvl = (jur_lvl_t const *)m->d_lvl;
   v->crv = (jur_crv_t const *)m->d_crv;
   v->ue = (jur_ue_t const *)m->d_ue;
@@ -255,8 +257,8 @@ int jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device)
 void jur_model_destroy(jur_model_t *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
-  if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_lvl = m->d_crv = m->d_ue = NULL;
-  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_lvl, m->d_crv, m->d_ue, m->d_atm, m->d_order, m->d_sort_tmp,
+  if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_pair_e0 = m->d_lvl = m->d_crv = m->d_ue = NULL;
+  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_pair_e0, m->d_lvl, m->d_crv, m->d_ue, m->d_atm, m->d_order, m->d_sort_tmp,
                   m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np, m->d_fov};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
     if (ptrs[i]) (void)hipFree(ptrs[i]);

@@ -481,22 +481,28 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
       for (int it = 0; it < tb->pair[i].lv[ip].nt; it++) nentry += tb->pair[i].lv[ip].cv[it].nu;
     }
   }
-  if (nentry >= (1L << 29) - 4 || ncurve >= (1L << 27) || nlevel >= (1L << 27)) {  /* kernels address with 32-bit byte offsets */
-    jur_set_error("tables too large for 32-bit byte offsets (%ld entries)", nentry);
+  /* The kernels address descriptors (16 B) with 32-bit byte offsets from the array's base, and table entries (8 B)
+   * with 32-bit byte offsets from the first entry of the (gas, channel) PAIR, whose 64-bit base is wave-uniform: any
+   * number of entries, pairs of at most TBLNP x TBLNT x TBLNU = 364 800. */
+  if (ncurve >= (1L << 27) || nlevel >= (1L << 27)) {
+    jur_set_error("tables too large for 32-bit descriptor offsets (%ld curves, %ld levels)", ncurve, nlevel);
     return JUR_EINVAL;
   }
   out->nlevel = nlevel; out->ncurve = ncurve; out->nentry = nentry;
   out->pair = (jur_int2 *)calloc(npair > 0 ? npair : 1, sizeof(jur_int2));
+  out->pair_e0 = (long long *)calloc(npair > 0 ? npair : 1, sizeof(long long));
   out->lvl = (jur_lvl_t *)calloc(nlevel + 2, sizeof(jur_lvl_t));
   out->crv = (jur_crv_t *)calloc(ncurve + 2, sizeof(jur_crv_t));
   out->ue = (jur_ue_t *)calloc(nentry + 2, sizeof(jur_ue_t));
-  if (!out->pair || !out->lvl || !out->crv || !out->ue) { jur_flat_free(out); return JUR_ENOMEM; }
+  if (!out->pair || !out->pair_e0 || !out->lvl || !out->crv || !out->ue) { jur_flat_free(out); return JUR_ENOMEM; }
   long L = 0, K = 0, E = 0;
   int sorted = 1, strict = 1;
   for (long i = 0; i < npair; i++) {
     jur_pair_t const *pr = &tb->pair[i];
     out->pair[i].a = pr->np;
     out->pair[i].b = (int)L;
+    out->pair_e0[i] = E;
+    long const E0 = E;
     for (int ip = 0; ip < pr->np; ip++, L++) {
       out->lvl[L].p = pr->lv[ip].p;
       out->lvl[L].nt = pr->lv[ip].nt;
@@ -507,7 +513,7 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
         jur_curve_t const *cv = &pr->lv[ip].cv[it];
         out->crv[K].t = cv->t;
         out->crv[K].nu = cv->nu;
-        out->crv[K].e0 = (int)E;
+        out->crv[K].e0 = (int)(E - E0);
         if (it > 0 && !(pr->lv[ip].cv[it - 1].t <= cv->t)) sorted = 0;
         if (it > 0 && !(pr->lv[ip].cv[it - 1].t < cv->t)) strict = 0;
         for (int iu = 0; iu < cv->nu; iu++, E++) {
@@ -531,14 +537,14 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
 }
 
 void jur_flat_free(jur_flat_t *f) {
-  free(f->pair); free(f->lvl); free(f->crv); free(f->ue);
+  free(f->pair); free(f->pair_e0); free(f->lvl); free(f->crv); free(f->ue);
   memset(f, 0, sizeof *f);
 }
 
 /* ---- compact binary cache (own format; upstream's cache is a raw dump of its dense 8.8 GB
  *      tbl_t, jr_binary_tables_io.h:213-233) ------------------------------------------------ */
 #define JUR_CACHE_MAGIC "JURASSIC-HIP compact emissivity tables\n"
-#define JUR_CACHE_VERSION 1
+#define JUR_CACHE_VERSION 2      /* 2: curve offsets count from the first entry of their pair */
 
 void jur_tables_cache_filename(char *out, size_t len, ctl_t const *ctl) {
   snprintf(out, len, "bin.jurassic-hip-tables-g%d-d%d", ctl->ng, ctl->nd);   /* cf. jr_binary_tables_io.h:12-16 */
@@ -641,9 +647,11 @@ int jur_tables_load(jur_tables_t **out, ctl_t const *ctl, char const *path) {
         fread(tb->sr, sizeof(double), (size_t)JUR_TBLNS * ctl->nd, in) != (size_t)JUR_TBLNS * ctl->nd ||
         fread(&sum, sizeof sum, 1, in) != 1) goto mismatch;
     /* rebuild the hierarchy, validating every extent and offset on the way */
+    long E0 = 0;                                   /* first entry of the pair: pairs lie one after the other */
     for (size_t i = 0; i < npair; i++) {
       int const np = fl.pair[i].a;
       long const L0 = fl.pair[i].b;
+      long pair_entries = 0;
       if (np < 0 || np > JUR_TBLNP || L0 < 0 || L0 + np > fl.nlevel) goto mismatch;
       jur_pair_t *pr = &tb->pair[i];
       if (np == 0) continue;
@@ -657,16 +665,18 @@ int jur_tables_load(jur_tables_t **out, ctl_t const *ctl, char const *path) {
         pr->lv[ip].nt = l->nt;
         for (int it = 0; it < l->nt; it++) {
           jur_crv_t const *c = &fl.crv[l->c0 + it];
-          if (c->nu < 0 || c->nu > JUR_TBLNU || c->e0 < 0 || (long)c->e0 + c->nu > fl.nentry) goto mismatch;
+          if (c->nu < 0 || c->nu > JUR_TBLNU || c->e0 != pair_entries || E0 + c->e0 + c->nu > fl.nentry) goto mismatch;
+          pair_entries += c->nu;
           jur_curve_t *cv = &pr->lv[ip].cv[it];
           cv->t = c->t;
           cv->nu = cv->cap = c->nu;
           cv->u = (float *)malloc(sizeof(float) * (c->nu > 0 ? c->nu : 1));
           cv->eps = (float *)malloc(sizeof(float) * (c->nu > 0 ? c->nu : 1));
           if (!cv->u || !cv->eps) { rc = JUR_ENOMEM; goto fail; }
-          for (int iu = 0; iu < c->nu; iu++) { cv->u[iu] = fl.ue[c->e0 + iu].u; cv->eps[iu] = fl.ue[c->e0 + iu].eps; }
+          for (int iu = 0; iu < c->nu; iu++) { cv->u[iu] = fl.ue[E0 + c->e0 + iu].u; cv->eps[iu] = fl.ue[E0 + c->e0 + iu].eps; }
         }
       }
+      E0 += pair_entries;
     }
     for (int id = 0; id < ctl->nd; id++) tb->have_sr[id] = 1;
     if (jur_tables_checksum(tb) != sum) goto mismatch;

@@ -76,6 +76,17 @@ def nadir_case(geom=None, **kw):
     return Case(NADIR_EMITTERS, NADIR_NU, os.path.join(GOLD, "nadir", "atm.tab"), g, **kw)
 
 
+def tau_atol(ref_tau):
+    """Absolute allowance for a path transmittance next to the relative 1e-9.  The algorithm forms a segment's
+    transmittance as (1 - eps) / tau: every look-up leaves ~1e-15 of ABSOLUTE rounding in eps, i.e. ~1e-15 / tau
+    relative in the path transmittance, over some hundred segments -- so the allowance grows as tau falls, from 1e-13
+    (tau of order one) to at most 5e-12 (tau <= 1e-4: two of 6 000 random configurations reach 1.2e-12 there, with
+    every variant of the kernels, old and new; the oracle's own result moves by that much when the view latitude
+    changes by 1e-13 degrees)."""
+    t = np.maximum(np.abs(np.asarray(ref_tau, dtype=np.float64)), 1e-300)
+    return 1e-13 + np.minimum(5e-16 / t, 5e-12)
+
+
 def rel_err(a, b):
     a, b = np.asarray(a), np.asarray(b)
     den = np.maximum(np.abs(b), 1e-300)

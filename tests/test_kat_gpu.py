@@ -176,8 +176,11 @@ def test_continua_on_the_window_edges(hip, oracle):
                     continue
                 strictly = [0 < nu < 4000, 0 < nu < 20000, 2120 < nu < 2605, 1360 < nu < 1805]
                 assert np.any(ref[k] != 0) or not strictly[k], (name, nu)    # (the N2 / O2 coefficients vanish at the edges)
-                # co2 is arithmetic only (same doubles); the others call exp / tanh / pow of the device library
-                tol = 0.0 if name == "co2" else 4e-15 if name in ("n2", "o2") else 2e-14
+                # co2 is arithmetic only (same doubles).  The others (round 3, jur_kernels.hip): exp through a 64-entry
+                # table and a degree-5 polynomial (~1 ulp), the quotients by T through one shared reciprocal (~2 ulp),
+                # tanh(x) as (1 - e) / (1 + e) with e = exp(-2x): relative error ~1e-16 / 2x, x = 0.7193876 nu / T --
+                # 2e-15 for the infrared channels, more for the 1 cm^-1 channel this test includes on purpose
+                tol = 0.0 if name == "co2" else 1e-14 if name in ("n2", "o2") else (5e-14 if nu >= 100 else 5e-13)
                 err = np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1e-300)
                 assert err.max() <= tol, (name, nu, err.max())
         m.close()
@@ -205,9 +208,10 @@ def test_source_function_update_gate_surface_and_brightness(hip, oracle):
         closed = tau_gas <= 1e-50                                                    # gate shut: nothing changes
         assert np.any(closed) and np.array_equal(rad[closed], rad0[closed]) and np.array_equal(tau[closed], tau0[closed])
         assert np.array_equal(rrad[closed], rad0[closed]) and np.array_equal(rtau[closed], tau0[closed])
-        # exp of the device library differs from libm's in the last place: eps = 1 - tau_gas exp(-beta) moves by ~1e-16
-        assert np.all(np.abs(rad - rrad) <= 4e-16 * (np.abs(rrad) + np.abs(rsrc)))
-        assert np.abs(tau - rtau).max() <= 4e-16
+        # the device's exp (table + degree-5 polynomial) differs from libm's in the last place: eps = 1 - tau_gas exp(-beta)
+        # moves by a few 1e-16
+        assert np.all(np.abs(rad - rrad) <= 1e-15 * (np.abs(rrad) + np.abs(rsrc)))
+        assert np.abs(tau - rtau).max() <= 1e-15
         # epilogue: surface term for tsurf > 0 (-999 = no ground hit), brightness temperature where asked
         tsurf = np.where(rng.uniform(size=n) < 0.5, t, -999.0)
         bbt = (rng.uniform(size=n) < 0.5).astype(np.float64)

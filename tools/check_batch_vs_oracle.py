@@ -30,6 +30,12 @@ for workload, n in (("limb_1e6", int(sys.argv[1]) if len(sys.argv) > 1 else 300_
                          rad_max_rel=float(common.rel_err(got["rad"][fin], ref["rad"][fin]).max()),
                          tau_max_abs=float(np.abs(got["tau"] - ref["tau"]).max()),
                          tp_max_abs=float(np.abs(got["tp"] - ref["tp"]).max()),
+                         # the suite's transmittance criterion (tests/test_parity_gpu.py): worst |dtau| / allowance, and the
+                         # worst |dtau| by decade of tau
+                         tau_worst_over_allowance=float((np.abs(got["tau"] - ref["tau"]) /
+                                                         (1e-9 * np.abs(ref["tau"]) + common.tau_atol(ref["tau"]))).max()),
+                         tau_abs_by_decade={"1e%d" % k: float(np.abs(got["tau"] - ref["tau"])[(ref["tau"] >= 10.0 ** k) & (ref["tau"] < 10.0 ** (k + 1))].max(initial=0))
+                                            for k in range(-10, 0)},
                          nonfinite=int((~np.isfinite(got["rad"])).sum()))
     print(workload, out[workload], flush=True)
 ok = all(v["np_equal"] and v["rad_max_rel"] < 1e-9 and v["tau_max_abs"] < 1e-9 and v["nonfinite"] == 0 for v in out.values())
