@@ -224,16 +224,9 @@ __device__ __forceinline__ int locate_axis_from(double const *__restrict__ xx, i
 // WANT_R: the caller interpolates more quantities on the same bracket; for a sorted axis (dir != 0: z strictly
 // monotone, bracket width non-zero) it gets rdz = RN(1 / (zb - za)) and every such interpolation, the
 // temperature's included, divides through it (lip_rcp: the same doubles, 3 instructions per quotient).
-// the exponential of the pressure interpolation (eip, jr_common.h:53-57): the device library's, or -- JUR_TRACE_EXP_TAB,
-// an A/B switch of the build -- the table form of the radiance update
-#ifdef JUR_TRACE_EXP_TAB
-#define TRACE_EXP(x) exp_tab(e2t, (x))
-#else
-#define TRACE_EXP(x) exp(x)
-#endif
-template <bool WANT_R = false, class Tab = Exp2Global>
+template <bool WANT_R = false>
 __device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, double z0, double &p, double &t, int dir,
-                                         int &hint, double *rdz = nullptr, Tab const &e2t = Tab()) {
+                                         int &hint, double *rdz = nullptr) {
   int const loc = dir ? locate_axis_from(v.atm_z + i0, n, z0, dir, hint) : locate_axis(v.atm_z + i0, n, z0);
   hint = loc;
   int const ip = i0 + loc;
@@ -244,10 +237,10 @@ __device__ __forceinline__ int intpol_pt(jur_view_t const &v, int i0, int n, dou
   if (WANT_R && dir) {
     double const r = 1. / (zb - za);
     *rdz = r;
-    p = (sl == sl) ? v.atm_p[ip] * TRACE_EXP(sl * (z0 - za)) : lip_rcp(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0, r);
+    p = (sl == sl) ? v.atm_p[ip] * exp(sl * (z0 - za)) : lip_rcp(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0, r);
     t = lip_rcp(za, v.atm_t[ip], zb, v.atm_t[ip + 1], z0, r);
   } else {
-    p = (sl == sl) ? v.atm_p[ip] * TRACE_EXP(sl * (z0 - za)) : lip(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0);
+    p = (sl == sl) ? v.atm_p[ip] * exp(sl * (z0 - za)) : lip(za, v.atm_p[ip], zb, v.atm_p[ip + 1], z0);
     t = lip(za, v.atm_t[ip], zb, v.atm_t[ip + 1], z0);
   }
   return ip;
@@ -456,7 +449,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
       }
 
       double p, t, rdz = 0;
-      int const ia = intpol_pt<true>(v, atm0, atmn, z, p, t, zdir, zhint, &rdz, L.e2t());
+      int const ia = intpol_pt<true>(v, atm0, atmn, z, p, t, zdir, zhint, &rdz);
       double const dsn = (np >= 1) ? 0.5 * (ds_p + ds) : ds * 0.5;   // redone for the point before the exit
       L.at(JUR_F_DS, np) = dsn;
       {  // remaining quantities on the same bracket (jr_common.h:557-567)
@@ -513,7 +506,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
                                 (j == 3) ? xh[2] + h : xh[2]};
           cart2geo(xq, zz, llon, llat);
           double rdzb = 0;
-          intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb, L.e2t());   // (lip_rcp == lip: same doubles as the plain search)
+          intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb);   // (lip_rcp == lip: same doubles as the plain search)
           double const nj = refractivity(pp, tt), n2 = quad_bcast<0>(nj);
           ngr[0] = div_rcp(quad_bcast<1>(nj) - n2, h, 1. / h);
           ngr[1] = div_rcp(quad_bcast<2>(nj) - n2, h, 1. / h);
@@ -521,7 +514,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
         } else {
         cart2geo(xh, zz, llon, llat);
         double rdzb = 0;
-        int const ib = intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb, L.e2t());
+        int const ib = intpol_pt<true>(v, atm0, atmn, zz, pp, tt, zdir, rhint, &rdzb);
         double const n2 = refractivity(pp, tt);
         // the three displaced probes lie 0.02 km away: almost always in the bracket just found, whose six
         // values are then reused instead of being looked up and loaded again
@@ -535,11 +528,10 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
           bool const inside = (zdir > 0) ? ((zz >= za || first) && (zz < zb || lastb))
                             : (zdir < 0) ? ((zz < za || first) && (zz >= zb || lastb)) : false;
           if (inside) {
-            auto const e2t = L.e2t();
-            pp = (sl == sl) ? pa * TRACE_EXP(sl * (zz - za)) : lip_rcp(za, pa, zb, pb, zz, rdzb);   // inside => sorted axis
+            pp = (sl == sl) ? pa * exp(sl * (zz - za)) : lip_rcp(za, pa, zb, pb, zz, rdzb);   // inside => sorted axis
             tt = lip_rcp(za, ta, zb, tb, zz, rdzb);
           } else {
-            intpol_pt<false>(v, atm0, atmn, zz, pp, tt, zdir, rhint, nullptr, L.e2t());
+            intpol_pt(v, atm0, atmn, zz, pp, tt, zdir, rhint);
           }
           ngr[i] = div_rcp(refractivity(pp, tt) - n2, h, 1. / h);
           xh[i] -= h;
@@ -603,8 +595,6 @@ struct LosWorkspace {
   double *los;
   size_t R;
   int r;
-  double const *e2;            // 2^(j/64) in LDS
-  __device__ __forceinline__ Exp2Lds e2t() const { return Exp2Lds{e2}; }
   __device__ __forceinline__ double &at(int field, int ip) const { return los[((size_t)field * NLOS + ip) * R + r]; }
   __device__ __forceinline__ size_t field_stride() const { return (size_t)NLOS * R; }
   __device__ __forceinline__ void begin_point(int) const {}
@@ -617,13 +607,10 @@ struct LosWorkspace {
 // launch carries enough rays (>= 4 x 131072) to fill them
 __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chunk_t c) {
   __shared__ double tr_sh[15][64];
-  __shared__ double e2_sh[64];
-  e2_sh[threadIdx.x & 63] = JUR_EXP2_64[threadIdx.x & 63];
-  __syncthreads();
   int const r = blockIdx.x * blockDim.x + threadIdx.x;   // slot in the chunk
   if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
-  LosWorkspace L{c.los, (size_t)c.stride, r, e2_sh};
+  LosWorkspace L{c.los, (size_t)c.stride, r};
   TraceResult const t = trace_ray(v, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray], c.geom[4][ray],
                                   c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
   c.np[r] = t.np;
@@ -1325,8 +1312,10 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
 // (FETCH_SIZE of the kernel -29 %).  The kernel waits on its dependent chains more than on HBM, so this is worth
 // 4 % of its time, not 29 (17.3 against 18.1 ms per 1e6 limb rays); one channel per workgroup remains for nd = 1.
 // The wave index is made uniform (readfirstlane) so that the channel constants stay in scalar registers.
+// 8 waves per SIMD (56 VGPRs, no scratch): a workgroup is 8 wavefronts, so anything above 64 VGPRs runs three
+// workgroups per CU instead of four; 13.1 ms per 1e6 limb rays against 14.7 ms at 69 VGPRs (A/B: -DJUR_COMBINE_WAVES=6)
 #ifndef JUR_COMBINE_WAVES
-#define JUR_COMBINE_WAVES 6
+#define JUR_COMBINE_WAVES 8
 #endif
 __global__ __launch_bounds__(512, JUR_COMBINE_WAVES) void jur_combine_group_kernel(jur_view_t v, jur_chunk_t c, int nsb, int CG, int SYNC) {   // SYNC: mask, see the loop
   int const nd = v.nd, ng = v.ng;
@@ -1456,7 +1445,6 @@ __device__ __forceinline__ bool first_active_lane() {
 
 // LOS fields of the workgroup's rays in the LDS ring [point % PEN_RING][field][ray]
 struct LosRing {
-  __device__ __forceinline__ Exp2Global e2t() const { return Exp2Global(); }
   double *ring;
   PenCtl *ctl;
   int *npr;
