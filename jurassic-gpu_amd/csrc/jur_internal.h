@@ -36,7 +36,7 @@ typedef struct {
   int pad;
 } jur_chan_t;
 
-/* LOS workspace: fields stored as [field][point][ray-in-chunk] (ray fastest). */
+/* LOS workspace: tiles of 64 ray slots, fields stored as [tile][point][field][64]. */
 enum { JUR_F_P = 0, JUR_F_T = 1, JUR_F_DS = 2, JUR_F_QH2O = 3, JUR_F_K = 4 /* + nw, then u[ng] */ };
 
 /* Read-only device view of a model; passed to kernels by value. */
@@ -78,8 +78,8 @@ typedef struct {
  * while the workspace arrays (np, tsurf, los) are indexed by slot. */
 typedef struct {
   int n;                        /* rays in this chunk                           */
-  int stride;                   /* Rt: ray stride of the LOS workspace          */
-  int stride_eps;               /* R: ray stride of the transmittance workspace */
+  int stride;                   /* Rt: slots the LOS workspace holds (multiple of 64)           */
+  int stride_eps;               /* R: slots the transmittance workspace holds (multiple of 64)  */
   long first;                   /* first ray id when order == NULL              */
   int const *order;             /* [n] ray ids of this chunk, or NULL           */
   double const *geom[7];        /* time, obsz, obslon, obslat, vpz, vplon, vplat; [nr] */
@@ -88,8 +88,8 @@ typedef struct {
   int *np_out;                  /* [nr] LOS points per ray, or NULL             */
   int *np;                      /* [n] LOS points per slot                      */
   double *tsurf;                /* [n]                                          */
-  double *los;                  /* [nfield][JUR_NLOS][stride]                   */
-  double *eps;                  /* [nd*ng][JUR_NLOS][stride] segment transmittances */
+  double *los;                  /* tiles of 64 slots: [slot / 64][JUR_NLOS][nfield][64]  */
+  double *eps;                  /* path transmittances, tiles of 64 slots: [slot / 64][JUR_NLOS][nd*ng][64] */
   int *status;                  /* device flag: bit0 = NLOS overflow            */
 } jur_chunk_t;
 

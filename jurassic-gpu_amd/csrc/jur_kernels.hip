@@ -590,13 +590,16 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
   return {np, tsurf, tpz, tplon, tplat};
 }
 
-// LOS fields in the HBM workspace, [field][point][ray slot]
+// LOS fields in the HBM workspace: tiles of 64 ray slots (one wavefront), [tile][point][field][64].  Everything a
+// wavefront reads or writes for one LOS point is one contiguous run of nfield x 512 B, and everything it touches in its
+// life lies within NLOS x nfield x 512 B (2 MB for ten fields): a handful of pages per wavefront, where the round-1/2
+// layout [field][point][ray] put every field of every point on a page of its own (rows 8 MB apart for 1e6 rays).
+__device__ __forceinline__ size_t los_tile_doubles(int nfield) { return (size_t)NLOS * nfield * 64; }
 struct LosWorkspace {
-  double *los;
-  size_t R;
-  int r;
-  __device__ __forceinline__ double &at(int field, int ip) const { return los[((size_t)field * NLOS + ip) * R + r]; }
-  __device__ __forceinline__ size_t field_stride() const { return (size_t)NLOS * R; }
+  double *tile;                 // first double of this wavefront's tile, + lane
+  int nfield;
+  __device__ __forceinline__ double &at(int field, int ip) const { return tile[((size_t)ip * nfield + field) * 64]; }
+  __device__ __forceinline__ size_t field_stride() const { return 64; }
   __device__ __forceinline__ void begin_point(int) const {}
   __device__ __forceinline__ void points_final(int) const {}
   __device__ __forceinline__ void ray_final(int, double) const {}
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
   int const r = blockIdx.x * blockDim.x + threadIdx.x;   // slot in the chunk
   if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
-  LosWorkspace L{c.los, (size_t)c.stride, r};
+  LosWorkspace L{c.los + (size_t)(r >> 6) * los_tile_doubles(JUR_F_K + v.nw + v.ng) + (r & 63), JUR_F_K + v.nw + v.ng};
   TraceResult const t = trace_ray(v, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray], c.geom[4][ray],
                                   c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
   c.np[r] = t.np;
@@ -1213,12 +1216,16 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   PairDesc<LDS> D{v.lvl, v.crv, v.ue + v.pair_e0[pair_idx], (unsigned)pd.b, 0u, 0u, 0u};
   stage_pair<LDS, RCPB>(v, pd, D);
   if (r >= c.n) return;
-  size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
-  size_t const Re = (size_t)c.stride_eps, fe = (size_t)NLOS * Re;
-  // planes of the workspace are addressed as (uniform row pointer) + lane offset
-  double const *const los_p = c.los + JUR_F_P * fs, *const los_t = c.los + JUR_F_T * fs,
-               *const los_u = c.los + (size_t)(JUR_F_K + v.nw + g) * fs;
-  double *const out = c.eps + (size_t)pr * fe;
+  // the workspaces are addressed as (wave-uniform pointer into this wavefront's tile) + lane offset
+  int const nfield = JUR_F_K + v.nw + v.ng;
+  int const tile = __builtin_amdgcn_readfirstlane(r >> 6);
+  unsigned const lane = (unsigned)(r & 63);
+  size_t const R = (size_t)nfield * 64;                              // doubles from one LOS point to the next
+  double const *const los_tile = c.los + (size_t)tile * los_tile_doubles(nfield);
+  double const *const los_p = los_tile + JUR_F_P * 64, *const los_t = los_tile + JUR_F_T * 64,
+               *const los_u = los_tile + (size_t)(JUR_F_K + v.nw + g) * 64;
+  size_t const Re = (size_t)npair * 64;                              // ... and from one point's transmittances to the next
+  double *const out = c.eps + (size_t)tile * NLOS * Re + (size_t)pr * 64;
   int const np = c.np[r];
   double tau_path = 1.0;
   unsigned br = 0, ia = 0, ib = 0;
@@ -1228,21 +1235,54 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   // reciprocal widths sit at 72 VGPRs already and keep loading at the point of use.
   constexpr bool AHEAD = RCPB || !WARM;
   double p_next = 0., t_next = 0.;
-  if (AHEAD && np > 0) { p_next = ldg<double>(los_p, r); t_next = ldg<double>(los_t, r); }
+  if (AHEAD && np > 0) { p_next = ldg<double>(los_p, lane); t_next = ldg<double>(los_t, lane); }
   for (int ip = 0; ip < np; ++ip) {
     size_t const o = (size_t)ip * R;
     double p, t;
     if constexpr (AHEAD) {
       p = p_next; t = t_next;
-      if (ip + 1 < np) { p_next = ldg<double>(los_p + o + R, r); t_next = ldg<double>(los_t + o + R, r); }
-    } else { p = ldg<double>(los_p + o, r); t = ldg<double>(los_t + o, r); }
-    double const u = ldg<double>(los_u + o, r);
+      if (ip + 1 < np) { p_next = ldg<double>(los_p + o + R, lane); t_next = ldg<double>(los_t + o + R, lane); }
+    } else { p = ldg<double>(los_p + o, lane); t = ldg<double>(los_t + o, lane); }
+    double const u = ldg<double>(los_u + o, lane);
     // what is carried and written is the gas's transmittance of the path up to and including this segment
     if constexpr (RCPB) tau_path = ega_eps_warm<LDS, true, true>(v, pd, D, tau_path, t, u, p, br, ia, ib);
     else if constexpr (WARM) tau_path *= ega_eps_warm<LDS, false>(v, pd, D, tau_path, t, u, p, br, ia, ib);
     else tau_path *= ega_eps_exact<LDS>(v, pd, D, tau_path, t, u, p);
-    *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)((unsigned)r * 8u)) = tau_path;
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)(lane * 8u)) = tau_path;
   }
+}
+
+// Everything the radiance update reads for one segment, requested together: the LOS fields of the point (one
+// contiguous run of the tile) and the path transmittances of the channel's gases, multiplied in the reference's gas
+// order (jr_common.h:272-278).  All loads are issued before the first value is used -- one memory latency per segment.
+// (Rounds 1-2 loaded each gas's transmittance inside the product loop, and the continua's columns inside their
+// branches: the compiler waited for each in turn, seven dependent round trips to HBM per segment, and the kernel sat
+// at half the bandwidth it asks for with idle vector units.)  Gases beyond the first eight take a second batch.
+struct SegmentIn { double p, t, ds, k, u_co2, q_h2o, u_h2o, pcur; };
+__device__ __forceinline__ SegmentIn load_segment(double const *__restrict__ row, double const *__restrict__ trow, unsigned lane,
+                                                  int f_k, int f_co2, int f_h2o, int ng, unsigned has_table) {
+  SegmentIn in;
+  in.p = ldg<double>(row + JUR_F_P * 64, lane);
+  in.t = ldg<double>(row + JUR_F_T * 64, lane);
+  in.ds = ldg<double>(row + JUR_F_DS * 64, lane);
+  in.k = ldg<double>(row + (size_t)f_k * 64, lane);
+  in.u_co2 = ldg<double>(row + (size_t)f_co2 * 64, lane);
+  in.q_h2o = ldg<double>(row + JUR_F_QH2O * 64, lane);
+  in.u_h2o = ldg<double>(row + (size_t)f_h2o * 64, lane);
+  double tg[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) tg[k] = (k < ng && ((has_table >> k) & 1u)) ? ldg<double>(trow + (size_t)k * 64, lane) : 1.0;
+  double pcur = 1.0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) pcur *= tg[k];           // (x * 1.0 == x: absent gases do not change the product)
+  for (int g0 = 8; g0 < ng; g0 += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) tg[k] = (g0 + k < ng && g0 + k < 32 && ((has_table >> (g0 + k)) & 1u)) ? ldg<double>(trow + (size_t)(g0 + k) * 64, lane) : 1.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) pcur *= tg[k];
+  }
+  in.pcur = pcur;
+  return in;
 }
 
 // jur_combine_kernel: one lane per ray, one channel per workgroup: continua, product of the gas
@@ -1268,10 +1308,12 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
   }
   if (r >= c.n) return;
   long const ray = c.order ? (long)c.order[r] : c.first + r;
-  size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
-  size_t const Re = (size_t)c.stride_eps, fe = (size_t)NLOS * Re;
-  double const *const los = c.los;
-  double const *const epsb = c.eps + (size_t)d * ng * fe;
+  int const nfield = JUR_F_K + v.nw + ng;
+  int const tile = __builtin_amdgcn_readfirstlane(r >> 6);
+  unsigned const lane = (unsigned)(r & 63);
+  size_t const R = (size_t)nfield * 64, Re = (size_t)nd * ng * 64;   // doubles from one LOS point to the next
+  double const *const los = c.los + (size_t)tile * los_tile_doubles(nfield);
+  double const *const epsb = c.eps + (size_t)tile * NLOS * Re + (size_t)d * ng * 64;
   jur_chan_t const ch = v.chan[d];
   int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
   bool const do_co2 = (v.fourbit & 8) && ch.co2_on, do_h2o = (v.fourbit & 4) && ch.h2o_on,
@@ -1282,22 +1324,18 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
   int const np = c.np[r];
   unsigned has_table = 0;                              // gases with a table for this channel (uniform)
   for (int g = 0; g < ng && g < 32; g++) has_table |= (v.pair[g * nd + d].a >= 2 ? 1u : 0u) << g;
+  int const f_co2 = f_u + (do_co2 ? v.ig_co2 : 0), f_h2o = f_u + (do_h2o ? v.ig_h2o : 0);
   for (int ip = 0; ip < np; ++ip) {
-    size_t const o = (size_t)ip * R;
-    auto L = [&](int field) { return ldg<double>(los + (size_t)field * fs + o, r); };
-    double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
-    double beta_ds = L(f_k) * ds;
-    if (do_co2) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
-    double const rt = rcp_t(t);
-    if (do_h2o) beta_ds += ctm_h2o(e2t, ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
-    if (do_n2) beta_ds += ctm_n2(e2t, ch, p, t, rt) * ds;
-    if (do_o2) beta_ds += ctm_o2(e2t, ch, p, t, rt) * ds;
-    double pcur = 1.0;
-    for (int g = 0; g < ng; g++)                       // jr_common.h:272-278
-      if ((has_table >> g) & 1u) pcur *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
-    double const tau_gas = segment_tau_gas(pcur, pprev);
-    pprev = pcur;
-    new_obs_step(e2t, tau_gas, beta_ds, planck_src(sr, t), rad, tau);
+    SegmentIn const in = load_segment(los + (size_t)ip * R, epsb + (size_t)ip * Re, lane, f_k, f_co2, f_h2o, ng, has_table);
+    double beta_ds = in.k * in.ds;
+    if (do_co2) beta_ds += ctm_co2(ch, in.p, in.t, in.u_co2);
+    double const rt = rcp_t(in.t);
+    if (do_h2o) beta_ds += ctm_h2o(e2t, ch, in.p, in.t, rt, in.q_h2o, in.u_h2o);
+    if (do_n2) beta_ds += ctm_n2(e2t, ch, in.p, in.t, rt) * in.ds;
+    if (do_o2) beta_ds += ctm_o2(e2t, ch, in.p, in.t, rt) * in.ds;
+    double const tau_gas = segment_tau_gas(in.pcur, pprev);
+    pprev = in.pcur;
+    new_obs_step(e2t, tau_gas, beta_ds, planck_src(sr, in.t), rad, tau);
   }
   ray_epilogue(sr, ch.nu, c.tsurf[r], v.write_bbt, rad, tau);
   if (masked) rad = __builtin_nan("");
@@ -1346,11 +1384,12 @@ __global__ __launch_bounds__(512, JUR_COMBINE_WAVES) void jur_combine_group_kern
   __syncthreads();
   int const npmax = *npmax_sh;
   long const ray = live ? (c.order ? (long)c.order[r] : c.first + r) : 0;
-  size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
-  size_t const Re = (size_t)c.stride_eps, fe = (size_t)NLOS * Re;
-  double const *const los = c.los;
+  int const nfield = JUR_F_K + v.nw + ng;
+  int const tile = sb * SUB + sub;                                   // (uniform: w is)
+  size_t const R = (size_t)nfield * 64, Re = (size_t)nd * ng * 64;   // doubles from one LOS point to the next
+  double const *const los = c.los + (size_t)tile * los_tile_doubles(nfield);
   int const dd = live_wave ? d : 0;
-  double const *const epsb = c.eps + (size_t)dd * ng * fe;
+  double const *const epsb = c.eps + (size_t)tile * NLOS * Re + (size_t)dd * ng * 64;
   jur_chan_t const ch = v.chan[dd];
   int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
   bool const do_co2 = (v.fourbit & 8) && ch.co2_on, do_h2o = (v.fourbit & 4) && ch.h2o_on,
@@ -1360,23 +1399,19 @@ __global__ __launch_bounds__(512, JUR_COMBINE_WAVES) void jur_combine_group_kern
   double rad = 0.0, tau = 1.0, pprev = 1.0;
   unsigned has_table = 0;
   for (int g = 0; g < ng && g < 32; g++) has_table |= (v.pair[g * nd + dd].a >= 2 ? 1u : 0u) << g;
+  int const f_co2 = f_u + (do_co2 ? v.ig_co2 : 0), f_h2o = f_u + (do_h2o ? v.ig_h2o : 0);
   for (int ip = 0; ip < npmax; ++ip) {
     if (ip < np) {
-      size_t const o = (size_t)ip * R;
-      auto L = [&](int field) { return ldg<double>(los + (size_t)field * fs + o, r); };
-      double const p = L(JUR_F_P), t = L(JUR_F_T), ds = L(JUR_F_DS);
-      double beta_ds = L(f_k) * ds;
-      if (do_co2) beta_ds += ctm_co2(ch, p, t, L(f_u + v.ig_co2));
-      double const rt = rcp_t(t);
-      if (do_h2o) beta_ds += ctm_h2o(e2t, ch, p, t, rt, L(JUR_F_QH2O), L(f_u + v.ig_h2o));
-      if (do_n2) beta_ds += ctm_n2(e2t, ch, p, t, rt) * ds;
-      if (do_o2) beta_ds += ctm_o2(e2t, ch, p, t, rt) * ds;
-      double pcur = 1.0;
-      for (int g = 0; g < ng; g++)
-        if ((has_table >> g) & 1u) pcur *= ldg<double>(epsb + (size_t)g * fe + (size_t)ip * Re, r);
-      double const tau_gas = segment_tau_gas(pcur, pprev);
-      pprev = pcur;
-      new_obs_step(e2t, tau_gas, beta_ds, planck_src(sr, t), rad, tau);
+      SegmentIn const in = load_segment(los + (size_t)ip * R, epsb + (size_t)ip * Re, (unsigned)lane, f_k, f_co2, f_h2o, ng, has_table);
+      double beta_ds = in.k * in.ds;
+      if (do_co2) beta_ds += ctm_co2(ch, in.p, in.t, in.u_co2);
+      double const rt = rcp_t(in.t);
+      if (do_h2o) beta_ds += ctm_h2o(e2t, ch, in.p, in.t, rt, in.q_h2o, in.u_h2o);
+      if (do_n2) beta_ds += ctm_n2(e2t, ch, in.p, in.t, rt) * in.ds;
+      if (do_o2) beta_ds += ctm_o2(e2t, ch, in.p, in.t, rt) * in.ds;
+      double const tau_gas = segment_tau_gas(in.pcur, pprev);
+      pprev = in.pcur;
+      new_obs_step(e2t, tau_gas, beta_ds, planck_src(sr, in.t), rad, tau);
     }
     if ((ip & SYNC) == SYNC) __syncthreads();      // SYNC = 2^k - 1 (0: a barrier after every segment; -1 never matches: none)
   }
@@ -1727,9 +1762,11 @@ __global__ __launch_bounds__(256) void jur_cg_kernel(jur_view_t v, jur_chunk_t c
   if (wave >= (long)c.n * ng) return;
   int const r = (int)(wave / ng), g = (int)(wave - (long)r * ng);
   long const ray = c.order ? (long)c.order[r] : c.first + r;
-  size_t const R = (size_t)c.stride, fs = (size_t)NLOS * R;
-  double const *const lp = c.los + JUR_F_P * fs + r, *const lt = c.los + JUR_F_T * fs + r,
-               *const lu = c.los + (size_t)(JUR_F_K + v.nw + g) * fs + r;
+  int const nfield = JUR_F_K + v.nw + ng;
+  size_t const R = (size_t)nfield * 64;                              // doubles from one LOS point of a ray to the next
+  double const *const tile = c.los + (size_t)(r >> 6) * los_tile_doubles(nfield) + (r & 63);
+  double const *const lp = tile + JUR_F_P * 64, *const lt = tile + JUR_F_T * 64,
+               *const lu = tile + (size_t)(JUR_F_K + v.nw + g) * 64;
   int const np = c.np[r];
   size_t const out = ((size_t)ray * ng + g) * NLOS;
   double cp = 0, ct = 0, cu = 0;                                         // carry of the previous chunks
@@ -2040,7 +2077,8 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
   // default, only when the channels fall into full groups of four: groups of two or three and ragged last groups were
   // measured slower than one channel per workgroup (tools/bench_combine_groups.py: 2 channels +7 %, 3 +17 %,
   // 6 = 4 + 2 +27 %).  A group size set through jur_tune_combine / JUR_COMBINE_GROUP is taken as it is.
-  bool const fits = g_combine_forced || (group == 4 && v->nd % 4 == 0);
+  // (with many channels the one ragged group at the end does not matter: 2378 = 594 x 4 + 2)
+  bool const fits = g_combine_forced || (group == 4 && (v->nd % 4 == 0 || v->nd >= 64));
   if (group > 0 && v->nd > 1 && fits && (long)c->n * v->nd >= g_combine_min_lanes) {
     int const CG = v->nd < group ? v->nd : group, SUB = 8 / CG, W = CG * SUB;
     int const nsb = (c->n + SUB * 64 - 1) / (SUB * 64), ncg = (v->nd + CG - 1) / CG;

@@ -707,7 +707,7 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
       c.order = order ? order + t0 + s0 : NULL;
       c.np = m->d_np + s0;
       c.tsurf = m->d_tsurf + s0;
-      c.los = m->d_los + s0;
+      c.los = m->d_los + (size_t)s0 * JUR_NLOS * m->nfield;   /* tiles of 64 slots, [tile][point][field][64]: s0 is a multiple of 64 */
       TIMED(1, jurk_launch_ega(&m->view, &c, s), "ega");
       TIMED(2, jurk_launch_combine(&m->view, &c, s), "combine");
     }
