@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
   int const np = c.np[r];
   unsigned has_table = 0;                              // gases with a table for this channel (uniform)
   for (int g = 0; g < ng && g < 32; g++) has_table |= (v.pair[g * nd + d].a >= 2 ? 1u : 0u) << g;
-  int const f_co2 = f_u + (do_co2 ? v.ig_co2 : 0), f_h2o = f_u + (do_h2o ? v.ig_h2o : 0);
+  int const f_co2 = do_co2 ? f_u + v.ig_co2 : JUR_F_P, f_h2o = do_h2o ? f_u + v.ig_h2o : JUR_F_P;   // (a field that always exists when the continuum is off)
   for (int ip = 0; ip < np; ++ip) {
     SegmentIn const in = load_segment(los + (size_t)ip * R, epsb + (size_t)ip * Re, lane, f_k, f_co2, f_h2o, ng, has_table);
     double beta_ds = in.k * in.ds;
@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(512, JUR_COMBINE_WAVES) void jur_combine_group_kern
   double rad = 0.0, tau = 1.0, pprev = 1.0;
   unsigned has_table = 0;
   for (int g = 0; g < ng && g < 32; g++) has_table |= (v.pair[g * nd + dd].a >= 2 ? 1u : 0u) << g;
-  int const f_co2 = f_u + (do_co2 ? v.ig_co2 : 0), f_h2o = f_u + (do_h2o ? v.ig_h2o : 0);
+  int const f_co2 = do_co2 ? f_u + v.ig_co2 : JUR_F_P, f_h2o = do_h2o ? f_u + v.ig_h2o : JUR_F_P;   // (a field that always exists when the continuum is off)
   for (int ip = 0; ip < npmax; ++ip) {
     if (ip < np) {
       SegmentIn const in = load_segment(los + (size_t)ip * R, epsb + (size_t)ip * Re, (unsigned)lane, f_k, f_co2, f_h2o, ng, has_table);
