@@ -626,7 +626,7 @@ def package_api(model, case, nr=1088, calls=40):
     bufs.close()
     return {"rays_per_call": n, "ms_per_call": 1e3 * dt, "value": n / dt, "unit": "rays/s", "callers": 1,
             "ms_per_call_with_python_marshalling": 1e3 * dt_py,
-            "note": "16 concurrent callers: profiles/r02_lanes_dropin_throughput.json"}
+            "note": "16 concurrent callers: profiles/r03_lanes_dropin_throughput.json"}
 
 
 if __name__ == "__main__":
