@@ -3,12 +3,12 @@
 //   jur_trace_kernel      one lane per ray: line-of-sight ray tracing through the 1-D
 //                         atmosphere (reference algorithm: jr_common.h:585-711), writes the
 //                         per-segment state p, T, ds, k, q_H2O, u[g] to the LOS workspace
-//                         in [field][point][ray] order (coalesced over rays), the tangent
+//                         (tiles of 64 ray slots, [tile][point][field][64]), the tangent
 //                         point, the point count and the surface temperature.
 //   jur_ega_kernel        one lane per ray, one (channel, gas) pair per workgroup: the sequential
 //                         emissivity-growth recurrence along the line of sight with its band
-//                         table look-ups (jr_common.h:237-280); writes the gas transmittance
-//                         of every segment.
+//                         table look-ups (jr_common.h:237-280); writes the gas's transmittance of the
+//                         path up to and including every segment.
 //   jur_combine_kernel    one lane per ray, one channel per workgroup: continua
 //                         (jr_common.h:315-390), product over gases, Planck source (:220-224),
 //                         radiance update (:293-300); surface term, brightness temperature and
@@ -32,12 +32,17 @@
 //   jur_intpol_kernel     regridding of a track / point-cloud atmosphere (intpol_atm, jurassic.c:675-804).
 //   jur_kat_*_kernel      known-answer hooks for tests: the device functions on arrays of inputs.
 //
-// All arithmetic is IEEE fp64 with the reference's operand order; tables are fp32 in memory.
-// Compiled with -ffp-contract=off so that no fused multiply-adds are formed that the
-// reference's x86-64 build does not form.  Where a division is replaced (div_rcp, div_finite,
-// div_const below) the replacement returns the same double as the division, and is checked to
-// (tools/compare_division_paths.py, tools/compare_builds.py); the one library function replaced
-// (pow with a constant base, pow_const) stays within the library's own error bound.
+// All arithmetic is IEEE fp64; tables are fp32 in memory.  Compiled with -ffp-contract=off so that no fused
+// multiply-adds are formed that the reference's x86-64 build does not form.
+//   * Ray tracing, and the look-ups on tables that are not strictly increasing, keep the reference's operand order
+//     throughout; where a division is replaced there (div_rcp, div_finite, div_const) the replacement returns the same
+//     double as the division (tools/compare_builds.py).
+//   * Since round 3 the look-up on strictly increasing tables (every table that passes the reference's row rule) and the
+//     radiance update spend part of the contract's tolerance -- 1e-6 relative on radiances, 1e-9 in the test suite -- on
+//     cheaper arithmetic: quotients through one Newton step, blends through reciprocal widths, the path transmittance
+//     carried as 1 - eps, one shared 1/T, exp through a table, tanh through exp (div_fast, lip_mulr, rcp_t, exp_tab,
+//     tanh_pos, segment_tau_gas below say what each costs in accuracy): 6e-12 relative on radiances against the
+//     bit-exact build.  The bit-exact look-ups remain as known-answer modes (jur_kat_ega_eps, modes 0 .. 2).
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -1191,9 +1196,9 @@ __device__ __forceinline__ void stage_pair(jur_view_t const &v, jur_int2 const p
 // ---------------------------------------------------------------------------------------
 // along-path integration in two kernels.  The emissivity-growth recurrence of every (ray, channel,
 // gas) triple is an independent sequential chain, so it gets its own lane -- ng x more lanes than
-// one lane per (ray, channel), half the registers, 5 waves per SIMD to hide the dependent table
-// loads -- and hands its per-segment transmittance to the combine kernel through HBM
-// ([pair][point][ray], ray fastest).  (A fused single kernel with the gases unrolled in one lane
+// one lane per (ray, channel), half the registers, 7 waves per SIMD to hide the dependent table
+// loads -- and hands its path transmittance after every segment to the combine kernel through HBM
+// (tiles of 64 ray slots, [tile][point][pair][64]).  (A fused single kernel with the gases unrolled in one lane
 // was measured 1.7x slower: 166+ VGPRs, 2-3 waves per SIMD.)
 //
 // jur_ega_kernel: one lane per ray, one (channel, gas) pair per workgroup.  Workgroups that
@@ -1287,7 +1292,7 @@ __device__ __forceinline__ SegmentIn load_segment(double const *__restrict__ row
 
 // jur_combine_kernel: one lane per ray, one channel per workgroup: continua, product of the gas
 // transmittances in the reference's order, Planck source, radiance update, epilogue.
-// 6 waves per SIMD: 18.2 ms per 1e6 limb rays against 20.6 ms at 4 and 20.4 ms at 7
+// (59 VGPRs since the exponentials go through exp_tab: 8 waves per SIMD)
 __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
   int const nd = v.nd, ng = v.ng;
   // same XCD-aware order as jur_ega_kernel: the nd workgroups of one ray block follow each other
