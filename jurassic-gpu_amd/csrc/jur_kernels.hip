@@ -53,6 +53,13 @@
 #define NLOS JUR_NLOS
 #define TBLNS JUR_TBLNS
 
+#ifndef JUR_SLOPES
+#define JUR_SLOPES 1
+#endif
+#ifndef JUR_UNIF
+#define JUR_UNIF 1
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------
@@ -120,6 +127,7 @@ __device__ __forceinline__ double div_fast(double a, double b) {
 __device__ __forceinline__ double lip_fast(double x0, double y0, double x1, double y1, double x) {
   return y0 + div_fast((x - x0) * (y1 - y0), x1 - x0);
 }
+__device__ __forceinline__ double lip_slope(double x0, double y0, double s, double x) { return __builtin_fma(x - x0, s, y0); }
 __device__ __forceinline__ double lip_mulr(double x0, double y0, double y1, double x, double r) {
   return y0 + ((x - x0) * (y1 - y0)) * r;
 }
@@ -664,6 +672,67 @@ __device__ __forceinline__ void ld_pair(void const *__restrict__ ue, unsigned id
   a = ab.a; b = ab.b;
 }
 
+// slope of the bracket [idx, idx+1]: WHICH = 0 du/deps (get_u), 1 deps/du (get_eps)
+template <int WHICH>
+__device__ __forceinline__ double ld_slope(void const *__restrict__ sl, unsigned idx) {
+  return *reinterpret_cast<double const *>(static_cast<char const *>(sl) + (size_t)(idx * 16u + WHICH * 8u));
+}
+
+// The same loads where the lanes of a wavefront may all want the same element -- rays sorted by tangent altitude walk
+// through the same brackets of the same curves nearly in step.  Then the element is fetched ONCE through the scalar
+// data cache (s_load into SGPRs) instead of 64 times through the vector L1, whose address pipeline -- 16 accesses per
+// gather -- is what the kernel runs out of next to its vector ALUs (profiles/pmc_current.json: TCP stalled or busy
+// > 90 % of the time).  Any lane that differs sends the wavefront through the gather; the values are the same.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ T ld_scalar(void const *__restrict__ base, unsigned byte0) {   // byte0: wave-uniform offset
+  typedef T const __attribute__((address_space(4))) *cptr;
+  return *(cptr)(unsigned long long)(static_cast<char const *>(base) + (size_t)byte0);
+}
+__device__ __forceinline__ bool all_lanes_at(unsigned idx, unsigned &idx0) {
+  idx0 = __builtin_amdgcn_readfirstlane(idx);
+  return __builtin_amdgcn_ballot_w64(idx != idx0) == 0;
+}
+// (Serving the lanes that disagree in rounds of scalar loads -- a "waterfall", one round per distinct element -- was
+// measured too: 59.6 ms with two rounds, 47.8 with one round and the gather for the rest, against 40.0 for the plain
+// all-or-nothing test below; each round waits for its own scalar load inside divergent control flow.)
+__device__ __forceinline__ Ue ld_ue_u(void const *__restrict__ ue, unsigned idx) {
+#if JUR_UNIF
+  unsigned i0;
+  if (all_lanes_at(idx, i0)) { f32x2 const v = ld_scalar<f32x2>(ue, i0 * 8u); return Ue{v.x, v.y}; }
+#endif
+  return ld_ue(ue, idx);
+}
+// the brackets of the two curves of a pressure level, requested together
+__device__ __forceinline__ void ld_pair2(void const *__restrict__ ue, unsigned ia, unsigned ib, Ue &a0, Ue &b0, Ue &a1, Ue &b1) {
+#if JUR_UNIF
+  unsigned fa, fb;
+  bool const ua = all_lanes_at(ia, fa), ub = all_lanes_at(ib, fb);
+  if (ua & ub) {
+    f32x4 const x = ld_scalar<f32x4>(ue, fa * 8u), y = ld_scalar<f32x4>(ue, fb * 8u);
+    a0 = Ue{x.x, x.y}; b0 = Ue{x.z, x.w}; a1 = Ue{y.x, y.y}; b1 = Ue{y.z, y.w};
+    return;
+  }
+#endif
+  ld_pair(ue, ia, a0, b0);
+  ld_pair(ue, ib, a1, b1);
+}
+template <int WHICH>
+__device__ __forceinline__ void ld_slope2(void const *__restrict__ sl, unsigned ia, unsigned ib, double &s0, double &s1) {
+#if JUR_UNIF
+  unsigned fa, fb;
+  bool const ua = all_lanes_at(ia, fa), ub = all_lanes_at(ib, fb);
+  if (ua & ub) {
+    s0 = ld_scalar<double>(sl, fa * 16u + WHICH * 8u);
+    s1 = ld_scalar<double>(sl, fb * 16u + WHICH * 8u);
+    return;
+  }
+#endif
+  s0 = ld_slope<WHICH>(sl, ia);
+  s1 = ld_slope<WHICH>(sl, ib);
+}
+
 template <bool ON_EPS>
 __device__ __forceinline__ double ukey(Ue const &e) { return ON_EPS ? (double)e.eps : (double)e.u; }
 
@@ -750,7 +819,7 @@ __device__ __forceinline__ void seek_curve_keys(void const *__restrict__ ue, uns
   if (!(up | down)) return;
   if (up) {
     if (i >= n - 2) return;
-    Ue const c = ld_ue(ue, e0 + i + 2);
+    Ue const c = ld_ue_u(ue, e0 + i + 2);
     double const kc = kkey<ON_EPS>(c);
     if (i + 2 >= n - 1 || kc > x) { ++i; a = b; b = c; ka = kb; kb = kc; return; }
     int lo = i + 2, hi, step = 2;
@@ -770,7 +839,7 @@ __device__ __forceinline__ void seek_curve_keys(void const *__restrict__ ue, uns
     ka = kkey<ON_EPS>(a); kb = kkey<ON_EPS>(b);
   } else {
     if (i <= 0) return;
-    Ue const c = ld_ue(ue, e0 + i - 1);
+    Ue const c = ld_ue_u(ue, e0 + i - 1);
     double const kc = kkey<ON_EPS>(c);
     if (i - 1 <= 0 || kc <= x) { --i; b = a; a = c; kb = ka; ka = kc; return; }
     int hi = i - 1, lo, step = 2;
@@ -800,6 +869,7 @@ template <bool LDS>
 struct PairDesc {
   void const *lvb, *cvb;       // global arrays
   void const *ueb;             // first (u, eps) entry of the pair
+  void const *slb;             // ... and its bracket slopes (strict tables)
   unsigned l0;                 // first level of the pair
   unsigned kbase;              // first curve of the pair (LDS copy starts there)
   __device__ __forceinline__ Lvl lvl(int i) const {
@@ -932,9 +1002,11 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
     int i[2] = {(int)(packed & 0xffffu), (int)(packed >> 16)};
     Ue a[2], b[2];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-      i[k] = min(i[k], n[k] - 2);
-      ld_pair(ueb, e0[k] + i[k], a[k], b[k]);
+    for (int k = 0; k < 2; k++) i[k] = min(i[k], n[k] - 2);
+    if constexpr (RCPB) ld_pair2(ueb, e0[0] + i[0], e0[1] + i[1], a[0], b[0], a[1], b[1]);
+    else {
+#pragma unroll
+      for (int k = 0; k < 2; k++) ld_pair(ueb, e0[k] + i[k], a[k], b[k]);
     }
     // get_u (jr_common.h:179-185): u at which the curve reaches eps; get_eps (:156-177): the curve's
     // emissivity at that u plus the segment's column -- the column only grows, so the second search
@@ -944,16 +1016,30 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
       double ka[2], kb[2];
 #pragma unroll
       for (int k = 0; k < 2; k++) seek_curve_keys<true, false>(ueb, e0[k], n[k], eps, i[k], a[k], b[k], ka[k], kb[k]);
+#if JUR_SLOPES
+      double s[2];
+      ld_slope2<0>(D.slb, e0[0] + i[0], e0[1] + i[1], s[0], s[1]);
+#endif
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         double const ya = kkey<false>(a[k]), yb = kkey<false>(b[k]);    // ... which serve get_eps's search as its keys
+#if JUR_SLOPES
+        x[k] = lip_slope(ka[k], ya, s[k], eps) + u;
+#else
         x[k] = lip_fast(ka[k], ya, kb[k], yb, eps) + u;
+#endif
         ka[k] = ya; kb[k] = yb;
       }
 #pragma unroll
       for (int k = 0; k < 2; k++) seek_curve_keys<false, true>(ueb, e0[k], n[k], x[k], i[k], a[k], b[k], ka[k], kb[k]);
+#if JUR_SLOPES
+      ld_slope2<1>(D.slb, e0[0] + i[0], e0[1] + i[1], s[0], s[1]);
+#pragma unroll
+      for (int k = 0; k < 2; k++) ec[k] = c01_num(lip_slope(ka[k], (double)a[k].eps, s[k], x[k]));
+#else
 #pragma unroll
       for (int k = 0; k < 2; k++) ec[k] = c01_num(lip_fast(ka[k], (double)a[k].eps, kb[k], (double)b[k].eps, x[k]));
+#endif
     } else {
 #pragma unroll
       for (int k = 0; k < 2; k++) seek_curve<true>(ueb, e0[k], n[k], eps, i[k], a[k], b[k]);
@@ -1029,9 +1115,9 @@ __device__ __forceinline__ double ega_eps_warm_quad(jur_view_t const &v, jur_int
   if constexpr (FAST) {
     bool const nan_in = (tau != tau || t != t || u != u || p != p);   // as ega_eps_warm: min/max clamps below
     seek_curve<true>(ueb, e0, n, eps, i, a, b);
-    double const x = lip_fast((double)a.eps, (double)a.u, (double)b.eps, (double)b.u, eps) + u;
+    double const x = lip_slope((double)a.eps, (double)a.u, ld_slope<0>(D.slb, e0 + i), eps) + u;
     seek_curve<false>(ueb, e0, n, x, i, a, b);
-    double const ec = c01_num(lip_fast((double)a.u, (double)a.eps, (double)b.u, (double)b.eps, x));
+    double const ec = c01_num(lip_slope((double)a.u, (double)a.eps, ld_slope<1>(D.slb, e0 + i), x));
     ix = (unsigned)i;
     double const ec0 = quad_bcast<0>(ec), ec1 = quad_bcast<1>(ec), ec2 = quad_bcast<2>(ec), ec3 = quad_bcast<3>(ec);
     double const eps_p0 = c01_num(lip_mulr(c00.t, ec0, ec1, t, 1. / (c01_.t - c00.t)));
@@ -1218,7 +1304,7 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   int const pair_idx = g * v.nd + d;
   jur_int2 const pd = v.pair[pair_idx];
   if (pd.a < 2) return;                          // no table: transmittance 1, the combine kernel knows
-  PairDesc<LDS> D{v.lvl, v.crv, v.ue + v.pair_e0[pair_idx], (unsigned)pd.b, 0u, 0u, 0u};
+  PairDesc<LDS> D{v.lvl, v.crv, v.ue + v.pair_e0[pair_idx], v.sl + v.pair_e0[pair_idx], (unsigned)pd.b, 0u, 0u, 0u};
   stage_pair<LDS, RCPB>(v, pd, D);
   if (r >= c.n) return;
   // the workspaces are addressed as (wave-uniform pointer into this wavefront's tile) + lane offset
@@ -1241,6 +1327,7 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   constexpr bool AHEAD = RCPB || !WARM;
   double p_next = 0., t_next = 0.;
   if (AHEAD && np > 0) { p_next = ldg<double>(los_p, lane); t_next = ldg<double>(los_t, lane); }
+
   for (int ip = 0; ip < np; ++ip) {
     size_t const o = (size_t)ip * R;
     double p, t;
@@ -1657,7 +1744,7 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
     // chain, one corner curve each ----
     constexpr int CS = (QUAD && WARM) ? 2 : 0;                  // lanes per chain = 1 << CS
     int const w = wave - 1, nl = (NE * 64) >> CS, me = (w * 64 + lane) >> CS;
-    PairDesc<false> D{v.lvl, v.crv, nullptr, 0u, 0u, 0u, 0u};
+    PairDesc<false> D{v.lvl, v.crv, nullptr, nullptr, 0u, 0u, 0u, 0u};
     for (int ip = 0;; ++ip) {
       int const cnt = wait_point(&ctl, ip);
       if (cnt <= ip) break;
@@ -1673,6 +1760,7 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
         if (pd.a < 2) continue;                                    // no table: the combine role knows
         D.l0 = (unsigned)pd.b;
         D.ueb = v.ue + v.pair_e0[g * nd + d];
+        D.slb = v.sl + v.pair_e0[g * nd + d];      // only read by the strict-table arithmetic, where v.sl is set
         double const p = slot[JUR_F_P * RB + r], t = slot[JUR_F_T * RB + r], u = slot[(JUR_F_K + v.nw + g) * RB + r];
         double const tau_path = st_tau[e];
         double tau_new;                                            // the gas's path transmittance after this segment
@@ -1798,6 +1886,17 @@ __global__ __launch_bounds__(256) void jur_cg_kernel(jur_view_t v, jur_chunk_t c
 // optionally grouped by the atmosphere slice the ray uses (neighbouring lanes then walk through
 // the same profile, i.e. the same table brackets)
 // ---------------------------------------------------------------------------------------
+// Bracket slopes of the emissivity curves, once per model: entry j gets the slopes of [entry j, entry j+1] in both
+// directions, formed from the fp32 entries with fp64 differences and IEEE divisions.  The last entry of a curve pairs
+// with the first of the next one; the look-up never reads that slot (its bracket index ends at nu - 2).
+__global__ __launch_bounds__(256) void jur_slopes_kernel(long long n, jur_ue_t const *__restrict__ ue, jur_sl_t *__restrict__ sl) {
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j + 1 < n; j += (long long)gridDim.x * blockDim.x) {
+    double const du = (double)ue[j + 1].u - (double)ue[j].u, de = (double)ue[j + 1].eps - (double)ue[j].eps;
+    sl[j].du_de = du / de;
+    sl[j].de_du = de / du;
+  }
+}
+
 __global__ __launch_bounds__(256) void jur_raykey_kernel(long nr, double const *__restrict__ geom,
                                                          double const *__restrict__ atm_time, int atm_np, int by_profile,
                                                          unsigned long long *__restrict__ key, int *__restrict__ id) {
@@ -1962,7 +2061,7 @@ __global__ __launch_bounds__(256) void jur_kat_ega_kernel(jur_view_t v, int g, i
                                                           double const *__restrict__ t, double const *__restrict__ u,
                                                           double const *__restrict__ p, int chain, double *__restrict__ out) {
   jur_int2 const pd = v.pair[g * v.nd + d];
-  PairDesc<LDS> D{v.lvl, v.crv, v.ue + v.pair_e0[g * v.nd + d], (unsigned)pd.b, 0u, 0u, 0u};
+  PairDesc<LDS> D{v.lvl, v.crv, v.ue + v.pair_e0[g * v.nd + d], v.sl + v.pair_e0[g * v.nd + d], (unsigned)pd.b, 0u, 0u, 0u};
   if (pd.a >= 2) stage_pair<LDS, RCPB>(v, pd, D);       // uniform branch; stage_pair ends in a barrier
   unsigned br = 0, ia = 0, ib = 0;
   auto one = [&](long i) {
@@ -2230,6 +2329,12 @@ extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int
     if (quad) hipLaunchKernelGGL((jur_pencil_kernel<false, true>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
     else hipLaunchKernelGGL((jur_pencil_kernel<false, false>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
   }
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_fill_slopes(jur_ue_t const *ue, jur_sl_t *sl, long long n, void *stream) {
+  long long const nb = (n + 255) / 256;
+  hipLaunchKernelGGL(jur_slopes_kernel, dim3((unsigned)(nb < 65536 ? (nb > 0 ? nb : 1) : 65536)), dim3(256), 0, (hipStream_t)stream, n, ue, sl);
   return (int)hipGetLastError();
 }
 

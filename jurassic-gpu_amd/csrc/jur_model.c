@@ -32,7 +32,7 @@ struct jur_model {
   jur_view_t view;              /* device pointers                               */
   long table_bytes;
   /* device allocations owned by the model */
-  void *d_chan, *d_sr, *d_pair, *d_pair_e0, *d_lvl, *d_crv, *d_ue;
+  void *d_chan, *d_sr, *d_pair, *d_pair_e0, *d_lvl, *d_crv, *d_ue, *d_sl;
   void *d_atm;                  /* one slab for the compact atmosphere           */
   int atm_cap;
   int atm_slices;               /* distinct time stamps in the atmosphere        */
@@ -188,10 +188,17 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   if (!rc) rc = upload(&m->d_lvl, fl.lvl, sizeof(jur_lvl_t) * (fl.nlevel + 2));
   if (!rc) rc = upload(&m->d_crv, fl.crv, sizeof(jur_crv_t) * (fl.ncurve + 2));
   if (!rc) rc = upload(&m->d_ue, fl.ue, sizeof(jur_ue_t) * (fl.nentry + 2));
+  if (!rc && fl.strict) {       /* bracket slopes for the strict-table look-up: 16 B per entry next to the 8 B of the entry */
+    rc = upload(&m->d_sl, NULL, sizeof(jur_sl_t) * (fl.nentry + 2));
+    if (!rc && (jurk_fill_slopes((jur_ue_t const *)m->d_ue, (jur_sl_t *)m->d_sl, fl.nentry + 2, NULL) || hipStreamSynchronize(NULL) != hipSuccess)) {
+      jur_set_error("cannot form the bracket slopes of the tables");
+      rc = JUR_EHIP;
+    }
+  }
   v->sorted_tables = fl.sorted;
   v->strict_tables = fl.strict;
   v->max_pair_curves = fl.max_pair_curves;
-  m->table_bytes = (long)(sizeof(jur_ue_t) * fl.nentry + 16 * fl.ncurve + 16 * fl.nlevel + 8 * npair);
+  m->table_bytes = (long)((sizeof(jur_ue_t) + (fl.strict ? sizeof(jur_sl_t) : 0)) * fl.nentry + 16 * fl.ncurve + 16 * fl.nlevel + 8 * npair);
   jur_flat_free(&fl);
   if (rc) { jur_model_destroy(m); return rc; }
   v->chan = (jur_chan_t const *)m->d_chan;
@@ -201,6 +208,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   v->lvl = (jur_lvl_t const *)m->d_lvl;
   v->crv = (jur_crv_t const *)m->d_crv;
   v->ue = (jur_ue_t const *)m->d_ue;
+  v->sl = (jur_sl_t const *)m->d_sl;
 
   m->nfield = JUR_F_K + v->nw + v->ng;
   m->chunk_rays = 1 << 21;      /* upper bound; the workspace budget sets the real size (1.4 M rays for 96 KB per ray).
@@ -257,8 +265,8 @@ int jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device)
 void jur_model_destroy(jur_model_t *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
-  if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_pair_e0 = m->d_lvl = m->d_crv = m->d_ue = NULL;
-  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_pair_e0, m->d_lvl, m->d_crv, m->d_ue, m->d_atm, m->d_order, m->d_sort_tmp,
+  if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_pair_e0 = m->d_lvl = m->d_crv = m->d_ue = m->d_sl = NULL;
+  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_pair_e0, m->d_lvl, m->d_crv, m->d_ue, m->d_sl, m->d_atm, m->d_order, m->d_sort_tmp,
                   m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np, m->d_fov};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
     if (ptrs[i]) (void)hipFree(ptrs[i]);
