@@ -106,6 +106,15 @@ def test_ega_eps_at_gates_and_axis_ends_is_bit_identical_in_every_mode(hip, orac
         print("mode 3 vs oracle, pair (%d, %d): worst |d(1 - eps_t)| = %.2e over %d inputs" % (ig, id_, worst, len(tau)))
         assert ok, (ig, id_, worst)
         assert np.array_equal(got3[tau < 1e-9], ref[tau < 1e-9])            # the gate answers 0 exactly in every mode
+        # wavefronts whose 64 lanes all carry the same inputs fetch their brackets and slopes through the scalar cache
+        # (ld_pair2 / ld_slope2 / ld_ue_u in jur_kernels.hip), wavefronts of mixed inputs gather them: same doubles
+        k = 512
+        rep = [np.repeat(x[:k], 64) for x in (tau, t, u, p)]
+        got_rep = m.kat_ega_eps(ig, id_, *rep, mode=3)
+        assert same_doubles(got_rep.reshape(k, 64)[:, 0], got3[:k]), ("mode 3: uniform wavefront == mixed wavefront", ig, id_)
+        assert same_doubles(got_rep, np.repeat(got_rep.reshape(k, 64)[:, 0], 64)), ("all lanes of a uniform wavefront agree", ig, id_)
+        got_rep = m.kat_ega_eps(ig, id_, *rep, mode=3, chain=True)          # ... and resuming from the previous look-up's brackets
+        assert same_doubles(got_rep.reshape(k, 64)[:, 0], got3[:k]), ("mode 3: chained uniform wavefront", ig, id_)
         # the searches resume from wherever the previous look-up ended: the result must not depend on that
         k = 4000
         for mode in (1, 2):

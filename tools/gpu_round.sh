@@ -2,6 +2,7 @@
 # One gpurun call of a development round: GPU tests, the bench line, latency / concurrency tables, optional PMC
 # passes.  A step that had to be killed ends the call (no further GPU work on a device in an unknown state).
 #   usage: tools/gpu_round.sh <tag> [tests] [bench] [small] [lanes] [pmc] [micro]      (default: tests bench)
+ulimit -c 0          # a faulting kernel must not leave a core file of the whole address space on the box
 mkdir -p gpurun_out
 OUTDIR=$(pwd)/gpurun_out
 TAG=${1:-r02}; shift

@@ -9,6 +9,7 @@ import re, sys
 t = open(sys.argv[1]).read()
 m = t[t.index("amdhsa.kernels:"):]
 for b in m.split("  - .agpr_count:")[1:]:
+    if "jur_" not in b.split(".name:")[1].split()[0]: continue
     n = re.search(r"\.name:\s+(\S+)", b).group(1)
     g = lambda k: re.search(r"\.%s:\s+(\d+)" % k, b).group(1)
     short = re.sub(r"^_ZN\d+_GLOBAL__N_1\d+", "", n)[:40]
