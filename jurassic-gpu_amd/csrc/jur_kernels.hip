@@ -39,10 +39,10 @@
 //     double as the division (tools/compare_builds.py).
 //   * Since round 3 the look-up on strictly increasing tables (every table that passes the reference's row rule) and the
 //     radiance update spend part of the contract's tolerance -- 1e-6 relative on radiances, 1e-9 in the test suite -- on
-//     cheaper arithmetic: quotients through one Newton step, blends through reciprocal widths, the path transmittance
-//     carried as 1 - eps, one shared 1/T, exp through a table, tanh through exp (div_fast, lip_mulr, rcp_t, exp_tab,
-//     tanh_pos, segment_tau_gas below say what each costs in accuracy): 6e-12 relative on radiances against the
-//     bit-exact build.  The bit-exact look-ups remain as known-answer modes (jur_kat_ega_eps, modes 0 .. 2).
+//     cheaper arithmetic: curve interpolations through bracket slopes formed once per model, blends through reciprocal
+//     widths, the path transmittance carried as 1 - eps, one shared 1/T, exp through a table, tanh through exp
+//     (lip_slope, lip_mulr, rcp_t, exp_tab, tanh_pos, segment_tau_gas below say what each costs in accuracy): 6e-12
+//     relative on radiances against the bit-exact build.  The bit-exact look-ups remain as known-answer modes (jur_kat_ega_eps, modes 0 .. 2).
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -52,13 +52,6 @@
 
 #define NLOS JUR_NLOS
 #define TBLNS JUR_TBLNS
-
-#ifndef JUR_SLOPES
-#define JUR_SLOPES 1
-#endif
-#ifndef JUR_UNIF
-#define JUR_UNIF 1
-#endif
 
 namespace {
 
@@ -107,10 +100,11 @@ __device__ __forceinline__ double lip_finite(double x0, double y0, double x1, do
 // The contract is 1e-6 relative on the radiances and the suite holds 1e-9; bit-identity with the reference's
 // divisions is not needed to stay 1e3 .. 1e6 times inside that, and it is what 40 % of the look-up's fp64 work went
 // into.  On tables whose axes and curves are strictly increasing (no zero-width bracket) the look-up uses:
-//   div_fast   a / b as a * r, r = rcp(b) refined by ONE Newton step: v_rcp_f64 is good to 2^-23 or better, the step
-//              squares that -- the quotient is good to ~2^-46 of itself, and it is the INCREMENT of an interpolation
-//              (at most a bracket width), so the interpolated value is good to a few 1e-15 of itself; 4 instructions
-//              with one v_rcp_f64 instead of 8;
+//   lip_slope  the eight curve interpolations as y0 + (x - x0) s, one fused multiply-add, with the bracket's slope s
+//              read from jur_sl_t (jur_slopes_kernel: the correctly rounded quotient of the bracket's fp64 differences,
+//              formed once per model) where rounds 1 - 2 divided (8 instructions) and the first round-3 version
+//              multiplied with a Newton-refined v_rcp_f64 (4, and the difference y1 - y0): good to an ulp or two of
+//              the interpolated value;
 //   lip_mulr   the p and T blends as y0 + ((x - x0) (y1 - y0)) r with r = RN(1 / (x1 - x0)): two roundings instead
 //              of the division's one, 1 instruction instead of 3;
 //   the path transmittance is carried as tau <- 1 - eps_t instead of tau <- tau * ((1 - eps_t) / tau): the same
@@ -119,14 +113,6 @@ __device__ __forceinline__ double lip_finite(double x0, double y0, double x1, do
 //   (channel, segment) in place of one per (channel, gas, segment)).
 // tests/test_kat_gpu.py holds this path against the bit-exact ones (modes 0 .. 2), which stay the known-answer
 // reference on the device.
-__device__ __forceinline__ double div_fast(double a, double b) {
-  double r = __builtin_amdgcn_rcp(b);
-  r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
-  return a * r;
-}
-__device__ __forceinline__ double lip_fast(double x0, double y0, double x1, double y1, double x) {
-  return y0 + div_fast((x - x0) * (y1 - y0), x1 - x0);
-}
 __device__ __forceinline__ double lip_slope(double x0, double y0, double s, double x) { return __builtin_fma(x - x0, s, y0); }
 __device__ __forceinline__ double lip_mulr(double x0, double y0, double y1, double x, double r) {
   return y0 + ((x - x0) * (y1 - y0)) * r;
@@ -698,15 +684,12 @@ __device__ __forceinline__ bool all_lanes_at(unsigned idx, unsigned &idx0) {
 // measured too: 59.6 ms with two rounds, 47.8 with one round and the gather for the rest, against 40.0 for the plain
 // all-or-nothing test below; each round waits for its own scalar load inside divergent control flow.)
 __device__ __forceinline__ Ue ld_ue_u(void const *__restrict__ ue, unsigned idx) {
-#if JUR_UNIF
   unsigned i0;
   if (all_lanes_at(idx, i0)) { f32x2 const v = ld_scalar<f32x2>(ue, i0 * 8u); return Ue{v.x, v.y}; }
-#endif
   return ld_ue(ue, idx);
 }
 // the brackets of the two curves of a pressure level, requested together
 __device__ __forceinline__ void ld_pair2(void const *__restrict__ ue, unsigned ia, unsigned ib, Ue &a0, Ue &b0, Ue &a1, Ue &b1) {
-#if JUR_UNIF
   unsigned fa, fb;
   bool const ua = all_lanes_at(ia, fa), ub = all_lanes_at(ib, fb);
   if (ua & ub) {
@@ -714,13 +697,11 @@ __device__ __forceinline__ void ld_pair2(void const *__restrict__ ue, unsigned i
     a0 = Ue{x.x, x.y}; b0 = Ue{x.z, x.w}; a1 = Ue{y.x, y.y}; b1 = Ue{y.z, y.w};
     return;
   }
-#endif
   ld_pair(ue, ia, a0, b0);
   ld_pair(ue, ib, a1, b1);
 }
 template <int WHICH>
 __device__ __forceinline__ void ld_slope2(void const *__restrict__ sl, unsigned ia, unsigned ib, double &s0, double &s1) {
-#if JUR_UNIF
   unsigned fa, fb;
   bool const ua = all_lanes_at(ia, fa), ub = all_lanes_at(ib, fb);
   if (ua & ub) {
@@ -728,7 +709,6 @@ __device__ __forceinline__ void ld_slope2(void const *__restrict__ sl, unsigned 
     s1 = ld_scalar<double>(sl, fb * 16u + WHICH * 8u);
     return;
   }
-#endif
   s0 = ld_slope<WHICH>(sl, ia);
   s1 = ld_slope<WHICH>(sl, ib);
 }
@@ -950,12 +930,12 @@ __device__ __forceinline__ double ega_eps_exact(jur_view_t const &v, jur_int2 co
 // segment's result, i.e. close to eps(x) on every curve, so its get_u search usually starts inside its
 // bracket (-10 % kernel time against resuming from get_u's position).
 // The two pressure levels are handled one after the other by a rolled loop, two curves (the temperature
-// bracket of the level) at a time: half the curve state is live, 72 VGPRs, 7 waves per SIMD (-5 %
+// bracket of the level) at a time: half the curve state is live, 70 VGPRs (62 with RCPB: 8 waves per SIMD), 7 waves per SIMD (-5 %
 // against all four curves side by side at 88 VGPRs).
 // RCPB (LDS copy present; p and T axes and, as stored in fp32, every curve strictly increasing: no bracket
 // has zero width): the three blends divide by multiplying with the reciprocal bracket widths staged in
 // LDS (div_rcp), the other nine divisions use div_finite.
-// RCPB is the strict-table arithmetic described at div_fast; with PATH the function returns the NEW path
+// RCPB is the strict-table arithmetic described at lip_slope; with PATH the function returns the NEW path
 // transmittance (1 - eps_t, or tau where the reference's look-up answers 1) instead of the segment's
 // transmittance (1 - eps_t) / tau -- what the kernels carry and write; the known-answer hook asks for the quotient.
 template <bool LDS, bool RCPB, bool PATH = false>
@@ -1016,30 +996,19 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
       double ka[2], kb[2];
 #pragma unroll
       for (int k = 0; k < 2; k++) seek_curve_keys<true, false>(ueb, e0[k], n[k], eps, i[k], a[k], b[k], ka[k], kb[k]);
-#if JUR_SLOPES
       double s[2];
       ld_slope2<0>(D.slb, e0[0] + i[0], e0[1] + i[1], s[0], s[1]);
-#endif
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         double const ya = kkey<false>(a[k]), yb = kkey<false>(b[k]);    // ... which serve get_eps's search as its keys
-#if JUR_SLOPES
         x[k] = lip_slope(ka[k], ya, s[k], eps) + u;
-#else
-        x[k] = lip_fast(ka[k], ya, kb[k], yb, eps) + u;
-#endif
         ka[k] = ya; kb[k] = yb;
       }
 #pragma unroll
       for (int k = 0; k < 2; k++) seek_curve_keys<false, true>(ueb, e0[k], n[k], x[k], i[k], a[k], b[k], ka[k], kb[k]);
-#if JUR_SLOPES
       ld_slope2<1>(D.slb, e0[0] + i[0], e0[1] + i[1], s[0], s[1]);
 #pragma unroll
       for (int k = 0; k < 2; k++) ec[k] = c01_num(lip_slope(ka[k], (double)a[k].eps, s[k], x[k]));
-#else
-#pragma unroll
-      for (int k = 0; k < 2; k++) ec[k] = c01_num(lip_fast(ka[k], (double)a[k].eps, kb[k], (double)b[k].eps, x[k]));
-#endif
     } else {
 #pragma unroll
       for (int k = 0; k < 2; k++) seek_curve<true>(ueb, e0[k], n[k], eps, i[k], a[k], b[k]);
@@ -1059,7 +1028,7 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
   }
   if constexpr (RCPB) {
     // the two level pressures are read from LDS again rather than kept through both levels: 4 VGPRs, which is what
-    // keeps the kernel at 7 waves per SIMD with the keys held as doubles
+    // kept the kernel at 7 waves per SIMD with the keys held as doubles (round 2; 8 waves at 62 VGPRs since the slopes)
     int q = ipr;
     asm volatile("" : "+v"(q));
     double const tau_new = 1. - c01_num(lip_mulr(D.lvl(q).p, eps_p0, eps_p1, p, D.rp(q)));
@@ -1075,7 +1044,7 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
 // the four curve emissivities are exchanged with DPP moves and every lane forms the blends -- the operations of
 // ega_eps_warm<false, false> in the same order, hence the same doubles.  State: br as there, ix = this lane's
 // position in its own curve.
-// FAST: the strict-table arithmetic of ega_eps_warm<.., true, true> (div_fast, lip_mulr with the reciprocal widths
+// FAST: the strict-table arithmetic of ega_eps_warm<.., true, true> (lip_slope, lip_mulr with the reciprocal widths
 // formed here by division -- the same doubles as the staged ones), returning the new path transmittance: the same
 // doubles as the batched kernel.  Otherwise the reference's arithmetic, returning the segment's transmittance.
 template <bool FAST>
@@ -1282,7 +1251,7 @@ __device__ __forceinline__ void stage_pair(jur_view_t const &v, jur_int2 const p
 // ---------------------------------------------------------------------------------------
 // along-path integration in two kernels.  The emissivity-growth recurrence of every (ray, channel,
 // gas) triple is an independent sequential chain, so it gets its own lane -- ng x more lanes than
-// one lane per (ray, channel), half the registers, 7 waves per SIMD to hide the dependent table
+// one lane per (ray, channel), half the registers, 7 - 8 waves per SIMD to hide the dependent table
 // loads -- and hands its path transmittance after every segment to the combine kernel through HBM
 // (tiles of 64 ray slots, [tile][point][pair][64]).  (A fused single kernel with the gases unrolled in one lane
 // was measured 1.7x slower: 166+ VGPRs, 2-3 waves per SIMD.)
@@ -1321,9 +1290,9 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   double tau_path = 1.0;
   unsigned br = 0, ia = 0, ib = 0;
   // p and T of a segment -- what the look-up needs first, for its bracket tests -- are requested one segment ahead
-  // (4 VGPRs: 72, still 7 waves per SIMD; -1.5 % kernel time); u, needed only after the first curve search, is not:
-  // with it the kernel drops to 6 waves (62.6 vs 60.9 ms when that was measured).  The warm variants without
-  // reciprocal widths sit at 72 VGPRs already and keep loading at the point of use.
+  // (4 VGPRs; -1.5 % kernel time); u, needed only after the first curve search, is not: in round 2 it cost a wavefront
+  // of occupancy (62.6 vs 60.9 ms), with the slopes it fits (64 VGPRs) and changes nothing (39.5 vs 39.8 ms).  The warm
+  // variants without reciprocal widths sit at 70 VGPRs and keep loading at the point of use.
   constexpr bool AHEAD = RCPB || !WARM;
   double p_next = 0., t_next = 0.;
   if (AHEAD && np > 0) { p_next = ldg<double>(los_p, lane); t_next = ldg<double>(los_t, lane); }

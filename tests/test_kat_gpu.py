@@ -13,8 +13,8 @@ end-to-end parity tests only reach by chance:
 The look-up is plain IEEE arithmetic in the reference's operand order, so ega_eps must come back BIT-IDENTICAL in
 modes 0 .. 2 (the reference's bisections; warm-started searches, descriptors from global memory / from LDS): these
 are the known-answer reference on the device.  Mode 3 -- what the kernels run on strictly increasing tables since
-round 3 -- replaces the reference's divisions by cheaper ones that are NOT correctly rounded (jur_kernels.hip,
-div_fast / lip_mulr) and is held to the same oracle within FAST_ABS on the path transmittance, a factor 1e6 inside
+round 3 -- replaces the reference's divisions by multiplications with stored slopes and reciprocal widths, NOT the
+correctly rounded quotients (jur_kernels.hip, lip_slope / lip_mulr), and is held to the same oracle within FAST_ABS on the path transmittance, a factor 1e6 inside
 the 1e-6 contract.  Functions that call exp / tanh / pow / log1p are held to a few ulp of the device math library.
 """
 import os
