@@ -15,7 +15,30 @@
 #include <strings.h>
 #include "jur_textio.h"
 
+#if defined(JUR_TOOL_LIMB) || defined(JUR_TOOL_NADIR)
+
+/* Both observation generators are one sweep -- time outside, a scan coordinate inside -- over keys read from the
+ * control file / command line; they differ in the keys' names and defaults, in what a row's scan coordinate means,
+ * and in when the row count is refused.  The sweeps accumulate `t += dt`, `x += dx` as upstream does. */
+enum { K_OBSZ, K_T0, K_T1, K_DT, K_X0, K_X1, K_DX, K_COUNT };
+typedef struct { char const *key, *dflt; } genkey_t;
+
 #if defined(JUR_TOOL_LIMB)
+/* scan coordinate: tangent altitude; the observer stands on the view point's meridian (limb.c:49-59) */
+static genkey_t const g_keys[K_COUNT] = {{"OBSZ", "780"}, {"T0", "0"}, {"T1", "0"}, {"DT", "1"}, {"Z0", "3"}, {"Z1", "68"}, {"DZ", "1"}};
+static void fill_row(obs_t *obs, int i, double obsz, double z) {
+  obs->vpz[i] = z;
+  obs->vplat[i] = 180 / M_PI * acos((JUR_RE + z) / (JUR_RE + obsz));
+}
+/* limb.c counts every row and refuses afterwards, naming the count */
+static void check_count(int nr, int final) { if (final && nr > JUR_NR) DIE("Too many rays! found %d, max is %d", nr, JUR_NR); }
+#else
+/* scan coordinate: latitude of the view point on the ground below the observer's meridian (nadir.c:51-58) */
+static genkey_t const g_keys[K_COUNT] = {{"OBSZ", "700"}, {"T0", "0"}, {"T1", "0"}, {"DT", "1"}, {"LAT0", "-8.01"}, {"LAT1", "8.01"}, {"DLAT", "0.18"}};
+static void fill_row(obs_t *obs, int i, double obsz, double lat) { (void)obsz; obs->vplat[i] = lat; }
+/* nadir.c refuses as soon as the last slot is taken */
+static void check_count(int nr, int final) { if (!final && nr >= JUR_NR) DIE("Too many rays!"); }
+#endif
 
 int main(int argc, char *argv[]) {
   if (argc < 3) DIE("Give parameters: <ctl> <obs>");
@@ -23,53 +46,20 @@ int main(int argc, char *argv[]) {
   obs_t *obs = (obs_t *)calloc(1, sizeof(obs_t));
   if (!ctl || !obs) DIE("Out of memory!");
   read_ctl(argc, argv, ctl);
-  double const obsz = scan_ctl(argc, argv, "OBSZ", -1, "780", NULL);
-  double const t0 = scan_ctl(argc, argv, "T0", -1, "0", NULL);
-  double const t1 = scan_ctl(argc, argv, "T1", -1, "0", NULL);
-  double const dt = scan_ctl(argc, argv, "DT", -1, "1", NULL);
-  double const z0 = scan_ctl(argc, argv, "Z0", -1, "3", NULL);
-  double const z1 = scan_ctl(argc, argv, "Z1", -1, "68", NULL);
-  double const dz = scan_ctl(argc, argv, "DZ", -1, "1", NULL);
+  double val[K_COUNT];
+  for (int k = 0; k < K_COUNT; k++) val[k] = scan_ctl(argc, argv, g_keys[k].key, -1, g_keys[k].dflt, NULL);
   int nr = 0;
-  for (double t = t0; t <= t1; t += dt)
-    for (double z = z0; z <= z1; z += dz) {
+  for (double t = val[K_T0]; t <= val[K_T1]; t += val[K_DT])
+    for (double x = val[K_X0]; x <= val[K_X1]; x += val[K_DX]) {
       if (nr < JUR_NR) {
         obs->time[nr] = t;
-        obs->obsz[nr] = obsz;
-        obs->vpz[nr] = z;
-        obs->vplat[nr] = 180 / M_PI * acos((JUR_RE + z) / (JUR_RE + obsz));   /* observer on the meridian, tangent at z */
+        obs->obsz[nr] = val[K_OBSZ];
+        fill_row(obs, nr, val[K_OBSZ], x);
       }
-      ++nr;
+      check_count(++nr, 0);
     }
-  if (nr > JUR_NR) DIE("Too many rays! found %d, max is %d", nr, JUR_NR);
+  check_count(nr, 1);
   obs->nr = nr;
-  write_obs(argv[2], ctl, obs);
-  free(ctl); free(obs);
-  return EXIT_SUCCESS;
-}
-
-#elif defined(JUR_TOOL_NADIR)
-
-int main(int argc, char *argv[]) {
-  if (argc < 3) DIE("Give parameters: <ctl> <obs>");
-  ctl_t *ctl = (ctl_t *)calloc(1, sizeof(ctl_t));
-  obs_t *obs = (obs_t *)calloc(1, sizeof(obs_t));
-  if (!ctl || !obs) DIE("Out of memory!");
-  read_ctl(argc, argv, ctl);
-  double const t0 = scan_ctl(argc, argv, "T0", -1, "0", NULL);
-  double const t1 = scan_ctl(argc, argv, "T1", -1, "0", NULL);
-  double const dt = scan_ctl(argc, argv, "DT", -1, "1", NULL);
-  double const obsz = scan_ctl(argc, argv, "OBSZ", -1, "700", NULL);
-  double const lat0 = scan_ctl(argc, argv, "LAT0", -1, "-8.01", NULL);
-  double const lat1 = scan_ctl(argc, argv, "LAT1", -1, "8.01", NULL);
-  double const dlat = scan_ctl(argc, argv, "DLAT", -1, "0.18", NULL);
-  for (double t = t0; t <= t1; t += dt)
-    for (double lat = lat0; lat <= lat1; lat += dlat) {
-      obs->time[obs->nr] = t;
-      obs->obsz[obs->nr] = obsz;
-      obs->vplat[obs->nr] = lat;            /* view point on the ground below the observer's meridian */
-      if (++obs->nr >= JUR_NR) DIE("Too many rays!");
-    }
   write_obs(argv[2], ctl, obs);
   free(ctl); free(obs);
   return EXIT_SUCCESS;

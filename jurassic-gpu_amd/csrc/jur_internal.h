@@ -22,6 +22,20 @@ typedef struct { double t; int nu; int e0; } jur_crv_t;   /* curve: nu (u,eps) e
                                                              (pair_e0[pair] + e0 in the ue array): 32 bits hold any
                                                              pair (<= 40 x 30 x 304 entries), the set may hold > 2^31 */
 
+/* Work item of jur_ega_group_kernel: up to JUR_EGA_NCH channels of ONE gas whose tables stand on the same (p, T)
+ * grid (same levels, same temperatures per level) -- what tables produced on one grid do.  A lane then owns a ray and
+ * the gas and walks the item's channels inside the segment loop: the LOS row, the p bracket, both T brackets are
+ * found once per segment and item instead of once per (channel, gas) pair (jr_common.h:241-246: the brackets do not
+ * depend on the curve). */
+#define JUR_EGA_NCH 4
+typedef struct {
+  int g, nch;
+  int flags;                    /* bit 0: every curve of the item's tables has >= 2 entries */
+  int pad;
+  int d[JUR_EGA_NCH];
+  long long e0[JUR_EGA_NCH];    /* first entry of pair (g, d[k]) in ue */
+} jur_item_t;
+
 /* Everything about the continua that depends on the channel only, reduced on
  * the host once per model with the reference's own expression order
  * (jr_common.h:318-325, 336-357, 367-372, 381-386). */
@@ -67,6 +81,9 @@ typedef struct {
   int max_pair_curves;          /* most curves any (gas, channel) pair has (LDS staging size)  */
   int strict_tables;            /* sorted, and p, T axes and (as stored, fp32) all curves strictly increasing:
                                    no bracket of the look-up has zero width                                     */
+  jur_item_t const *ega_items;  /* [ega_nitems] channel groups on a shared (p, T) grid, or NULL: one pair per workgroup */
+  int ega_nitems;
+  int ega_nch;                  /* channels of the largest item (1: nothing is shared)                           */
   /* atmosphere, compact SoA of atm_np points */
   int atm_np;
   int atm_sorted;               /* time stamps non-decreasing and z strictly monotone inside every slice */
@@ -172,6 +189,8 @@ typedef struct {
   jur_ue_t *ue;
 } jur_flat_t;
 int  jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out);
+/* channel groups on a shared (p, T) grid, at most nch channels each (malloc'ed; pairs without a table are in no item) */
+int  jur_flat_group_items(jur_flat_t const *f, int ng, int nd, int nch, jur_item_t **items, int *nitems, int *max_nch);
 void jur_flat_free(jur_flat_t *f);
 
 void jur_tables_cache_filename(char *out, size_t len, ctl_t const *ctl);

@@ -1313,6 +1313,179 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// jur_ega_group_kernel (round 4): one lane per (ray, gas), walking the channels of an ITEM -- up to JUR_EGA_NCH
+// channels whose tables of this gas stand on the same (p, T) grid (jur_flat_group_items) -- inside the segment loop.
+// What depends on the ray, the gas and the grid only is done once per segment and item instead of once per
+// (channel, gas) pair: the three LOS loads (p, T, u[g]), the pressure bracket, the two temperature brackets
+// (jr_common.h:241-246 -- the brackets do not depend on the curve), the NaN test of the inputs, the differences
+// p - p0, T - T0 of the three blends.  Per channel there remain the four curve walks with their blends: the same
+// operations on the same operands in the same order as ega_eps_warm<.., true, true>, hence the same doubles (the
+// test suite compares the two kernels bit for bit).
+// LDS per workgroup: the grid (levels {p, nt, first curve RELATIVE to the pair}, curve temperatures, reciprocal
+// bracket widths), per channel the curves' {nu, first entry}, and the chain state {path transmittance, curve
+// positions} of every (lane, channel): the channel loop is rolled, its state cannot live in registers.
+// Strict tables only (the arithmetic of lip_slope / lip_mulr); everything else keeps jur_ega_kernel.
+// ---------------------------------------------------------------------------------------
+
+// LDS of a workgroup of `block` lanes: grid {levels, curve temperatures, reciprocal T widths, reciprocal p widths},
+// first entries of the curves per channel (4 B each: a curve's length is the distance to the next one's start),
+// chain state [channel][lane] as two 8-byte arrays
+__host__ __device__ inline size_t ega_group_lds_bytes(int max_pair_curves, int nch, int block) {
+  size_t const capC = (size_t)max_pair_curves + 4;
+  return 16 * (size_t)JUR_TBLNP + 8 * capC * 2 + 8 * (size_t)JUR_TBLNP + ((4 * capC * nch + 15) & ~(size_t)15) + 16 * (size_t)block * nch;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(1024, WAVES) void jur_ega_group_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
+  int const nitems = v.ega_nitems;
+  int const BLOCK = (int)blockDim.x;
+  int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
+  int const rb = (sq / nitems) * 8 + xcd, it = sq - (sq / nitems) * nitems;   // ray block, item: uniform
+  if (rb >= nrb) return;
+  jur_item_t const *const item = v.ega_items + it;
+  int const g = item->g, nch = item->nch;
+  bool const all_curves = item->flags & 1;         // every curve of the item's tables has >= 2 entries (uniform)
+  int const capC = v.max_pair_curves + 4;
+  Lvl *const sL = reinterpret_cast<Lvl *>(jur_lds);
+  double *const sT = reinterpret_cast<double *>(jur_lds + 16 * JUR_TBLNP), *const sRT = sT + capC, *const sRP = sRT + capC;
+  int *const sE0 = reinterpret_cast<int *>(sRP + JUR_TBLNP);
+  // chain state, [channel][lane] with 8-byte elements: conflict-free 64-bit LDS accesses
+  double *const sTau = reinterpret_cast<double *>(jur_lds + 16 * JUR_TBLNP + 16 * (size_t)capC + 8 * JUR_TBLNP +
+                                                  ((4 * (size_t)capC * v.ega_nch + 15) & ~(size_t)15));
+  unsigned *const sPos = reinterpret_cast<unsigned *>(sTau + (size_t)v.ega_nch * BLOCK);   // [level 0 / 1][channel][lane]
+  jur_int2 const pd0 = v.pair[g * v.nd + item->d[0]];
+  int const npl = pd0.a;                           // >= 2: pairs without a table are in no item
+  {
+    Lvl const *const gl = reinterpret_cast<Lvl const *>(v.lvl) + pd0.b;
+    int const kb0 = gl[0].c0;
+    Lvl const last = gl[npl - 1];
+    int const ncrv = last.c0 + last.nt - kb0;
+    Crv const *const gc = reinterpret_cast<Crv const *>(v.crv) + kb0;
+    for (int i = threadIdx.x; i < npl; i += BLOCK) { Lvl l = gl[i]; l.c0 -= kb0; sL[i] = l; }
+    for (int i = threadIdx.x; i < ncrv + 2; i += BLOCK) sT[i] = i < ncrv ? gc[i].t : 0.;
+    // reciprocal widths exactly as stage_pair forms them (entries that straddle two axes are never used)
+    for (int i = threadIdx.x; i + 1 < npl; i += BLOCK) sRP[i] = 1. / (gl[i + 1].p - gl[i].p);
+    for (int i = threadIdx.x; i + 1 < ncrv; i += BLOCK) sRT[i] = 1. / (gc[i + 1].t - gc[i].t);
+    for (int k = 0; k < nch; k++) {
+      jur_int2 const pdk = v.pair[g * v.nd + item->d[k]];
+      Crv const *const gck = reinterpret_cast<Crv const *>(v.crv) + reinterpret_cast<Lvl const *>(v.lvl)[pdk.b].c0;
+      int const end = gck[ncrv - 1].e0 + gck[ncrv - 1].nu;            // the curves of a pair follow each other in ue
+      for (int i = threadIdx.x; i < ncrv + 4; i += BLOCK) sE0[(size_t)k * capC + i] = i < ncrv ? gck[i].e0 : end;
+    }
+    __syncthreads();
+  }
+  int const r = rb * BLOCK + threadIdx.x;
+  if (r >= c.n) return;
+  int const nfield = JUR_F_K + v.nw + v.ng;
+  int const tile = __builtin_amdgcn_readfirstlane(r >> 6);
+  unsigned const lane = (unsigned)(r & 63);
+  size_t const R = (size_t)nfield * 64;
+  double const *const los_tile = c.los + (size_t)tile * los_tile_doubles(nfield);
+  double const *const los_p = los_tile + JUR_F_P * 64, *const los_t = los_tile + JUR_F_T * 64,
+               *const los_u = los_tile + (size_t)(JUR_F_K + v.nw + g) * 64;
+  size_t const Re = (size_t)v.nd * v.ng * 64;
+  double *const out_tile = c.eps + (size_t)tile * NLOS * Re;
+  int const np = c.np[r];
+  double *const mytau = sTau + threadIdx.x;
+  unsigned *const mypos = sPos + threadIdx.x;
+  int const HS = v.ega_nch * BLOCK;                 // from a chain's positions on level l0 to those on l1
+  for (int k = 0; k < nch; k++) { mytau[k * BLOCK] = 1.0; mypos[k * BLOCK] = 0u; mypos[HS + k * BLOCK] = 0u; }
+  // the item's fields inside the segment loop come through the scalar cache (constant address space: a plain load
+  // behind the loop's stores is a vector load of a uniform value)
+  unsigned const item_byte = (unsigned)it * (unsigned)sizeof(jur_item_t);
+  unsigned br = 0;
+
+  for (int ip = 0; ip < np; ++ip) {
+    size_t const o = (size_t)ip * R;
+    // (no request one segment ahead as in jur_ega_kernel: the row's latency is spread over the item's channels)
+    double const p = ldg<double>(los_p + o, lane), t = ldg<double>(los_t + o, lane), u = ldg<double>(los_u + o, lane);
+    // ---- once per segment: the brackets of the shared grid
+    int ipr = min((int)(br & 0xffu), npl - 2);
+    Lvl l0 = sL[ipr], l1 = sL[ipr + 1];
+    if ((p < l0.p) | (p >= l1.p)) {
+      while (p < l0.p && ipr > 0) { --ipr; l1 = l0; l0 = sL[ipr]; }
+      while (p >= l1.p && ipr < npl - 2) { ++ipr; l0 = l1; l1 = sL[ipr + 1]; }
+    }
+    bool const valid = (l0.nt >= 2) & (l1.nt >= 2);                 // else the look-up answers "no change"
+    int it0 = max(min((int)((br >> 8) & 0xffu), l0.nt - 2), 0), it1 = max(min((int)((br >> 16) & 0xffu), l1.nt - 2), 0);
+    double T00 = sT[l0.c0 + it0], T01 = sT[l0.c0 + it0 + 1], T10 = sT[l1.c0 + it1], T11 = sT[l1.c0 + it1 + 1];
+    if (valid && ((t < T00) | (t >= T01) | (t < T10) | (t >= T11))) {
+      while (t < T00 && it0 > 0) { --it0; T01 = T00; T00 = sT[l0.c0 + it0]; }
+      while (t >= T01 && it0 < l0.nt - 2) { ++it0; T00 = T01; T01 = sT[l0.c0 + it0 + 1]; }
+      while (t < T10 && it1 > 0) { --it1; T11 = T10; T10 = sT[l1.c0 + it1]; }
+      while (t >= T11 && it1 < l1.nt - 2) { ++it1; T10 = T11; T11 = sT[l1.c0 + it1 + 1]; }
+    }
+    br = (unsigned)ipr | ((unsigned)it0 << 8) | ((unsigned)it1 << 16);
+    int const kc0 = l0.c0 + it0, kc1 = l1.c0 + it1;
+    double const dp = p - l0.p, dt0 = t - T00, dt1 = t - T10;      // (x - x0) of the three blends
+    bool const nan_in = (t != t) | (u != u) | (p != p);
+    // ---- per channel: the four curve walks and the blends
+#pragma unroll 1
+    for (int k = 0; k < nch; k++) {
+      double const tau = mytau[k * BLOCK];
+      unsigned *const pos = mypos + k * BLOCK;       // [0]: the chain's positions in level l0's curve pair, [HS]: l1's
+      unsigned const ku = (unsigned)__builtin_amdgcn_readfirstlane(k);
+      double tau_new = tau;
+      if (tau < 1e-9) tau_new = 0.;
+      else if (valid) {
+        int const *const ne = sE0 + (size_t)k * capC;
+        bool curves_ok = true;
+        if (!all_curves) {
+          int const a0 = ne[kc0], a1 = ne[kc0 + 1], a2 = ne[kc0 + 2], b0 = ne[kc1], b1 = ne[kc1 + 1], b2 = ne[kc1 + 2];
+          curves_ok = (a1 - a0 >= 2) & (a2 - a1 >= 2) & (b1 - b0 >= 2) & (b2 - b1 >= 2);
+        }
+        if (curves_ok) {
+          if (nan_in || tau != tau) tau_new = __builtin_nan("");
+          else {
+            long long const pe0 = ld_scalar<long long>(v.ega_items, item_byte + (unsigned)offsetof(jur_item_t, e0) + ku * 8u);
+            void const *const ueb = v.ue + pe0, *const slb = v.sl + pe0;
+            double const eps = 1 - tau;
+            double eps_p0 = 0, eps_p1 = 0;
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+              int const kc = h ? kc1 : kc0;
+              int const ea = ne[kc], eb = ne[kc + 1], ec_ = ne[kc + 2];
+              unsigned const packed = pos[h ? HS : 0];
+              unsigned const e0[2] = {(unsigned)ea, (unsigned)eb};
+              int const n[2] = {eb - ea, ec_ - eb};
+              int i[2] = {(int)(packed & 0xffffu), (int)(packed >> 16)};
+              Ue a[2], bb[2];
+#pragma unroll
+              for (int q = 0; q < 2; q++) i[q] = min(i[q], n[q] - 2);
+              ld_pair2(ueb, e0[0] + i[0], e0[1] + i[1], a[0], bb[0], a[1], bb[1]);
+              double x[2], ec[2], ka[2], kb[2], s[2];
+#pragma unroll
+              for (int q = 0; q < 2; q++) seek_curve_keys<true, false>(ueb, e0[q], n[q], eps, i[q], a[q], bb[q], ka[q], kb[q]);
+              ld_slope2<0>(slb, e0[0] + i[0], e0[1] + i[1], s[0], s[1]);
+#pragma unroll
+              for (int q = 0; q < 2; q++) {
+                double const ya = kkey<false>(a[q]), yb = kkey<false>(bb[q]);
+                x[q] = lip_slope(ka[q], ya, s[q], eps) + u;
+                ka[q] = ya; kb[q] = yb;
+              }
+#pragma unroll
+              for (int q = 0; q < 2; q++) seek_curve_keys<false, true>(ueb, e0[q], n[q], x[q], i[q], a[q], bb[q], ka[q], kb[q]);
+              ld_slope2<1>(slb, e0[0] + i[0], e0[1] + i[1], s[0], s[1]);
+#pragma unroll
+              for (int q = 0; q < 2; q++) ec[q] = c01_num(lip_slope(ka[q], (double)a[q].eps, s[q], x[q]));
+              pos[h ? HS : 0] = (unsigned)i[0] | ((unsigned)i[1] << 16);
+              // lip_mulr(T0, ec0, ec1, t, rt) with its (t - T0) formed above
+              double const e = c01_num(ec[0] + ((h ? dt1 : dt0) * (ec[1] - ec[0])) * sRT[kc]);
+              if (h) eps_p1 = e; else eps_p0 = e;
+            }
+            tau_new = 1. - c01_num(eps_p0 + (dp * (eps_p1 - eps_p0)) * sRP[br & 0xffu]);
+          }
+        }
+      }
+      mytau[k * BLOCK] = tau_new;
+      int const dk = ld_scalar<int>(v.ega_items, item_byte + (unsigned)offsetof(jur_item_t, d) + ku * 4u);
+      double *const out = out_tile + (size_t)(dk * v.ng + g) * 64;
+      *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)(lane * 8u)) = tau_new;
+    }
+  }
+}
+
 // Everything the radiance update reads for one segment, requested together: the LOS fields of the point (one
 // contiguous run of the tile) and the path transmittances of the channel's gases, multiplied in the reference's gas
 // order (jr_common.h:272-278).  All loads are issued before the first value is used -- one memory latency per segment.
@@ -2096,8 +2269,54 @@ extern "C" int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void
   return (int)hipGetLastError();
 }
 
+// dynamic LDS beyond 64 KB needs the attribute once per kernel AND per device (models may live on several GPUs of one
+// process, their lanes launch from several threads); `raised` holds one bit per device for the caller's kernel set
+static int raise_lds_limit(std::mutex &mu, unsigned long long &raised, void const *const *funcs, int nfunc, bool needed) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return (int)hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if ((raised >> dev) & 1ull) return 0;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < nfunc && e == hipSuccess; i++) e = hipFuncSetAttribute(funcs[i], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  if (e != hipSuccess) { (void)hipGetLastError(); return needed ? (int)e : 0; }
+  raised |= 1ull << dev;
+  return 0;
+}
+
+// Channel groups on a shared (p, T) grid (jur_ega_group_kernel) when the model has any and its tables are strictly
+// increasing; workgroup size from the LDS the chain states need (JUR_EGA_BLOCK overrides; JUR_EGA_GROUP=0 switches the
+// kernel off).  Returns -1 when the call is not for it.
+static int launch_ega_group(jur_view_t const *v, jur_chunk_t const *c, hipStream_t s) {
+  static int const env_group = getenv("JUR_EGA_GROUP") ? atoi(getenv("JUR_EGA_GROUP")) : -1;      // A/B switches, read once
+  static int const env_block = getenv("JUR_EGA_BLOCK") ? atoi(getenv("JUR_EGA_BLOCK")) : 0;
+  static int const env_waves = getenv("JUR_EGA_WAVES") ? atoi(getenv("JUR_EGA_WAVES")) : 0;
+  if (!v->ega_items || v->ega_nitems <= 0 || v->ega_nch < 2 || !v->strict_tables || env_group == 0 || getenv("JUR_EGA_NO_RCP") ||
+      getenv("JUR_EGA_NO_LDS"))
+    return -1;
+  int const block = (env_block >= 64 && env_block <= 1024 && env_block % 64 == 0) ? env_block : 448;
+  int const waves = env_waves >= 6 && env_waves <= 8 ? env_waves : 7;
+  size_t const lds = ega_group_lds_bytes(v->max_pair_curves, v->ega_nch, block);
+  if (lds > 128 * 1024) return -1;
+  static std::mutex mu;
+  static unsigned long long raised = 0;
+  void const *const funcs[] = {reinterpret_cast<void const *>(&jur_ega_group_kernel<6>), reinterpret_cast<void const *>(&jur_ega_group_kernel<7>),
+                               reinterpret_cast<void const *>(&jur_ega_group_kernel<8>)};
+  int const e = raise_lds_limit(mu, raised, funcs, 3, lds > 64 * 1024);
+  if (e) return e;
+  int const nrb = (c->n + block - 1) / block;
+  unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * v->ega_nitems);
+  if (waves == 6) hipLaunchKernelGGL((jur_ega_group_kernel<6>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
+  else if (waves == 7) hipLaunchKernelGGL((jur_ega_group_kernel<7>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
+  else hipLaunchKernelGGL((jur_ega_group_kernel<8>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
+  return (int)hipGetLastError();
+}
+
 extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
   if (c->n <= 0 || v->ng <= 0) return 0;
+  {
+    int const e = launch_ega_group(v, c, (hipStream_t)stream);
+    if (e >= 0) return e;
+  }
   int const block = 256;
   int const nrb = (c->n + block - 1) / block, npair = v->nd * v->ng;
   unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * npair);
@@ -2275,21 +2494,13 @@ extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int
   hipStream_t s = (hipStream_t)stream;
   int const atm_cap = pencil_atm_cap(v);
   long const lds_all = lds + 8L * (7 + v->ng + v->nw) * atm_cap;
-  {  // dynamic LDS beyond 64 KB needs the attribute once per kernel AND per device (models may live on several
-     // GPUs of one process, their lanes launch from several threads)
+  {
     static std::mutex mu;
-    static unsigned long long raised = 0;                 // one bit per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return (int)hipErrorInvalidDevice;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!((raised >> dev) & 1ull)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<void const *>(&jur_pencil_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      if (e != hipSuccess) { (void)hipGetLastError(); if (lds_all > 64 * 1024) return (int)e; }
-      else raised |= 1ull << dev;
-    }
+    static unsigned long long raised = 0;                 // one bit per device, read and written under mu
+    void const *const funcs[] = {reinterpret_cast<void const *>(&jur_pencil_kernel<true, true>), reinterpret_cast<void const *>(&jur_pencil_kernel<true, false>),
+                                 reinterpret_cast<void const *>(&jur_pencil_kernel<false, true>), reinterpret_cast<void const *>(&jur_pencil_kernel<false, false>)};
+    int const e = raise_lds_limit(mu, raised, funcs, 4, lds_all > 64 * 1024);
+    if (e) return e;
   }
   if (v->sorted_tables) {
     if (quad) hipLaunchKernelGGL((jur_pencil_kernel<true, true>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);

@@ -32,7 +32,7 @@ struct jur_model {
   jur_view_t view;              /* device pointers                               */
   long table_bytes;
   /* device allocations owned by the model */
-  void *d_chan, *d_sr, *d_pair, *d_pair_e0, *d_lvl, *d_crv, *d_ue, *d_sl;
+  void *d_chan, *d_sr, *d_pair, *d_pair_e0, *d_lvl, *d_crv, *d_ue, *d_sl, *d_items;
   void *d_atm;                  /* one slab for the compact atmosphere           */
   int atm_cap;
   int atm_slices;               /* distinct time stamps in the atmosphere        */
@@ -195,6 +195,17 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
       rc = JUR_EHIP;
     }
   }
+  if (!rc && fl.strict) {       /* channels of a gas whose tables stand on one (p, T) grid: jur_ega_group_kernel walks them together */
+    jur_item_t *items = NULL;
+    int nitems = 0, max_nch = 0, want = JUR_EGA_NCH;
+    if (getenv("JUR_EGA_GROUP") && atoi(getenv("JUR_EGA_GROUP")) >= 1) want = atoi(getenv("JUR_EGA_GROUP"));
+    rc = jur_flat_group_items(&fl, ctl->ng, ctl->nd, want, &items, &nitems, &max_nch);
+    if (!rc && max_nch >= 2) {
+      rc = upload(&m->d_items, items, sizeof(jur_item_t) * nitems);
+      if (!rc) { v->ega_items = (jur_item_t const *)m->d_items; v->ega_nitems = nitems; v->ega_nch = max_nch; }
+    }
+    free(items);
+  }
   v->sorted_tables = fl.sorted;
   v->strict_tables = fl.strict;
   v->max_pair_curves = fl.max_pair_curves;
@@ -265,8 +276,8 @@ int jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device)
 void jur_model_destroy(jur_model_t *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
-  if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_pair_e0 = m->d_lvl = m->d_crv = m->d_ue = m->d_sl = NULL;
-  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_pair_e0, m->d_lvl, m->d_crv, m->d_ue, m->d_sl, m->d_atm, m->d_order, m->d_sort_tmp,
+  if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_pair_e0 = m->d_lvl = m->d_crv = m->d_ue = m->d_sl = m->d_items = NULL;
+  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_pair_e0, m->d_lvl, m->d_crv, m->d_ue, m->d_sl, m->d_items, m->d_atm, m->d_order, m->d_sort_tmp,
                   m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np, m->d_fov};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
     if (ptrs[i]) (void)hipFree(ptrs[i]);

@@ -536,6 +536,59 @@ int jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out) {
   return JUR_OK;
 }
 
+/* Do pairs a and b stand on the same (p, T) grid: same levels, same number of curves per level, same temperatures?
+ * (Compared as doubles, exactly: a shared bracket must be THE bracket of every channel that shares it.) */
+static int same_grid(jur_flat_t const *f, long a, long b) {
+  if (f->pair[a].a != f->pair[b].a) return 0;
+  jur_lvl_t const *la = f->lvl + f->pair[a].b, *lb = f->lvl + f->pair[b].b;
+  for (int i = 0; i < f->pair[a].a; i++) {
+    if (la[i].p != lb[i].p || la[i].nt != lb[i].nt) return 0;
+    jur_crv_t const *ca = f->crv + la[i].c0, *cb = f->crv + lb[i].c0;
+    for (int k = 0; k < la[i].nt; k++)
+      if (ca[k].t != cb[k].t) return 0;
+  }
+  return 1;
+}
+
+int jur_flat_group_items(jur_flat_t const *f, int ng, int nd, int nch, jur_item_t **items, int *nitems, int *max_nch) {
+  *items = NULL; *nitems = 0; *max_nch = 0;
+  if (nch < 1) nch = 1;
+  if (nch > JUR_EGA_NCH) nch = JUR_EGA_NCH;
+  long const npair = (long)ng * nd;
+  jur_item_t *out = (jur_item_t *)calloc(npair > 0 ? npair : 1, sizeof(jur_item_t));
+  /* per gas: the grid classes met so far, each with the representative pair and its open item */
+  long *rep = (long *)malloc(sizeof(long) * (nd > 0 ? nd : 1));
+  int *open = (int *)malloc(sizeof(int) * (nd > 0 ? nd : 1));
+  if (!out || !rep || !open) { free(out); free(rep); free(open); return JUR_ENOMEM; }
+  int n = 0;
+  for (int g = 0; g < ng; g++) {
+    int nclass = 0;
+    for (int d = 0; d < nd; d++) {
+      long const i = (long)g * nd + d;
+      if (f->pair[i].a < 2) continue;            /* no table: the look-up answers 1, nothing to do */
+      int c = 0;
+      while (c < nclass && !same_grid(f, rep[c], i)) c++;
+      if (c == nclass) { rep[c] = i; open[c] = -1; nclass++; }
+      if (open[c] < 0) { open[c] = n++; out[open[c]].g = g; out[open[c]].nch = 0; out[open[c]].flags = 1; }
+      jur_item_t *it = &out[open[c]];
+      {  /* curves shorter than two entries make the look-up answer "no change": the kernel tests for them only
+            where an item has any */
+        jur_lvl_t const *lv = f->lvl + f->pair[i].b;
+        for (int ip = 0; ip < f->pair[i].a; ip++)
+          for (int k = 0; k < lv[ip].nt; k++)
+            if (f->crv[lv[ip].c0 + k].nu < 2) it->flags &= ~1;
+      }
+      it->e0[it->nch] = f->pair_e0[i];
+      it->d[it->nch++] = d;
+      if (it->nch > *max_nch) *max_nch = it->nch;
+      if (it->nch == nch) open[c] = -1;
+    }
+  }
+  free(rep); free(open);
+  *items = out; *nitems = n;
+  return JUR_OK;
+}
+
 void jur_flat_free(jur_flat_t *f) {
   free(f->pair); free(f->pair_e0); free(f->lvl); free(f->crv); free(f->ue);
   memset(f, 0, sizeof *f);

@@ -3,6 +3,7 @@
 # passes.  A step that had to be killed ends the call (no further GPU work on a device in an unknown state).
 #   usage: tools/gpu_round.sh <tag> [tests] [bench] [small] [lanes] [pmc] [micro]      (default: tests bench)
 ulimit -c 0          # a faulting kernel must not leave a core file of the whole address space on the box
+make -s -C jurassic-gpu_amd/csrc clean-variants 2>/dev/null   # stale experiment builds do not belong to the measured tree
 mkdir -p gpurun_out
 OUTDIR=$(pwd)/gpurun_out
 TAG=${1:-r02}; shift
