@@ -80,6 +80,7 @@ def parse_args(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--no-package-api", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] side measurement of the N = 1 line")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / sharding / gather rehearsal on the CPU (gloo): no library, no GPU, the forward "
                          "model replaced by a checksum of each ray's geometry; the line says dry_run")
@@ -414,6 +415,7 @@ def main(argv):
     case = build_case(workload, workload_rays(workload, np.arange(lo, hi)))   # this rank's rows of the ONE global set
     nd = case.ctl.nd
 
+    memory = None
     if dry:
         model = None
 
@@ -429,6 +431,10 @@ def main(argv):
         from jurassic_hip import lib
         model = lib.Model(case.ctl, case.lib_tables(), device=dev.index)
         model.set_atm(case.atm)
+        # Memory plan of this rank, made while only the tables are resident: what the run itself will allocate beside
+        # the model's workspace (the call's arrays, the copies of the determinism check, rank 0's gather target and its
+        # sampled re-computation) is set aside, the workspace budget takes the rest up to the library's default.
+        memory = plan_memory(lib, model, dev.index, nrays, nd, total if (use_dist and rank == 0) else 0)
         d_geom = torch.from_numpy(np.ascontiguousarray(case.geom.T)).to(dev)       # [7][nr]
         d_rad = torch.zeros((nrays, nd), dtype=torch.float64, device=dev)
         d_tau = torch.zeros((nrays, nd), dtype=torch.float64, device=dev)
@@ -492,7 +498,13 @@ def main(argv):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, mismatches = float(t[0].item()), int(t[1].item())
     peers = [None] * world
-    me = dict(rank=rank, local_rank=local_rank, world_size=world, pid=os.getpid(), rays=[lo, hi])
+    me = dict(rank=rank, local_rank=local_rank, world_size=world, pid=os.getpid(), rays=[lo, hi],
+              backend=(dist.get_backend() if use_dist else None))
+    if not dry:     # which physical device this rank computed on: N ranks must show N distinct PCI bus ids
+        props = torch.cuda.get_device_properties(dev)
+        me["device"] = dict(index=dev.index, name=props.name, pci_bus_id=memory["pci_bus_id"],
+                            uuid=str(getattr(props, "uuid", "")) or None)
+        me["memory"] = {k: v for k, v in memory.items() if k != "pci_bus_id"}
     if use_dist:
         dist.all_gather_object(peers, me)
     else:
@@ -579,12 +591,76 @@ def main(argv):
                 out["value_device_resident"] = out["value"]
             if world == 1 and not args.no_package_api:
                 out["package_api"] = package_api(model, case)
+            if world == 1 and workload == "limb_1e6" and not args.no_extra:
+                # configs[1] beside the headline, driver-timed like it (about a second of GPU): the mid-size regime,
+                # where a launch does not fill the chip
+                out["extra"] = {"nadir_1e5": side_workload("nadir_1e5", dev, steps=20, warmup=3)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()          # rank 0 may still have been in its CPU-side bookkeeping
         dist.destroy_process_group()
     return 0
+
+
+def plan_memory(lib, model, device, nrays, nd, gathered_rows):
+    """Sets the model's workspace budget from what the device has free right now minus what this run allocates itself;
+    returns the figures for the line.  Refuses a run that cannot fit instead of letting an allocation fail mid-way."""
+    info = lib.device_info(device)
+    own = nrays * (7 + 2 * nd + 3) * 8 + nrays * 4            # geometry, rad, tau, tp, np of the call
+    own += 2 * nrays * nd * 8                                 # the copies the determinism check keeps
+    own += gathered_rows * nd * 8                             # rank 0: the gather target
+    own += 4200 * (7 + 2 * nd + 3) * 8 * 2                    # rank 0: the sampled rows it re-computes
+    reserve = own + (4 << 30)                                 # allocator slack, sort buffers, RCCL's own buffers
+    default = 128 << 30
+    budget = min(default, info["free"] - reserve)
+    if budget < (1 << 30):
+        raise SystemExit("bench.py: device %d has %.1f GiB free, the run needs %.1f GiB beside a workspace of at least 1 GiB"
+                         % (device, info["free"] / 2**30, reserve / 2**30))
+    model.set_workspace_budget(budget)
+    return dict(pci_bus_id=info["pci_bus_id"], device_total_bytes=info["total"], free_bytes_after_tables=info["free"],
+                table_bytes=model.table_bytes(), own_arrays_bytes=own, workspace_budget_bytes=budget,
+                workspace_budget_lowered=budget < default)
+
+
+def side_workload(workload, dev, steps, warmup):
+    """A second workload measured in the same process after the headline (device-resident, event-timed kernels)."""
+    import numpy as np
+    import torch
+    from jurassic_hip import lib
+    n = WORKLOADS[workload]["total"]
+    case = build_case(workload, workload_rays(workload, np.arange(n)))
+    nd = case.ctl.nd
+    model = lib.Model(case.ctl, case.lib_tables(), device=dev.index)
+    model.set_atm(case.atm)
+    d_geom = torch.from_numpy(np.ascontiguousarray(case.geom.T)).to(dev)
+    d_rad = torch.zeros((n, nd), dtype=torch.float64, device=dev)
+    d_tau, d_tp = torch.zeros_like(d_rad), torch.zeros((3, n), dtype=torch.float64, device=dev)
+    d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    model.reserve(n)
+
+    def step():
+        d_rad.zero_()
+        model.formod_device(n, d_geom.data_ptr(), d_rad.data_ptr(), d_tau.data_ptr(), d_tp.data_ptr(), 0,
+                            d_status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    model.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms = model.kernel_ms()
+    ok = int(d_status.item()) == 0 and bool(torch.isfinite(d_rad).all())
+    model.close()
+    if not ok:
+        raise SystemExit("side workload %s: NLOS overflow or a non-finite radiance" % workload)
+    return {"value": n * steps / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+            "config": {"workload": workload, "rays_total": n, "channels": nd, "emitters": case.ctl.ng},
+            "kernels": {k: {"avg_launch_ms": kms[k + "_ms"] / max(1, kms[k + "_launches"]), "launches": kms[k + "_launches"]}
+                        for k in ("trace", "ega", "combine")}}
 
 
 def host_inclusive(model, case, steps, device_ms):

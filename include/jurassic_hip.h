@@ -128,6 +128,30 @@ int  jur_formod_device(jur_model_t *m, long nr, double const *d_geom,
                        double *d_rad, double *d_tau, double *d_tp, int *d_np,
                        int *d_status, void *stream);
 
+/* ---- several GPUs in one process ------------------------------------------------------------------------------
+ * The reference's device loop lives inside formod_GPU (GPUdrivers.cu:344-358: one OpenMP thread per device, every
+ * device given the same package); SURVEY.md section 8e asks for "one host process, one stream set per device" with the
+ * rays partitioned.  models[0 .. nmodel) are models of the same control block and tables, normally one per device
+ * (several on one device are allowed: that is how a one-GPU box rehearses the path); each needs the atmosphere
+ * (jur_models_set_atm).  Rays are dealt in CONTIGUOUS ranges whose boundaries equalise the estimated number of
+ * line-of-sight points (jur_multi_balance: straight-line path through the atmosphere's altitude range in steps of
+ * min(RAYDS, RAYDZ / |cos a|)), not the number of rays -- a tangent-height scan in its natural order has 122 .. 393
+ * points per ray.  Results are the single-model results bit for bit.
+ *
+ * jur_formod_host_multi: host arrays as jur_formod_host; one host thread per model, every share written straight
+ *   into the caller's arrays (pinned arrays move in place), no gather.
+ * jur_formod_device_multi: all arrays in device memory of models[0]'s GPU (layout as jur_formod_device).  Share 0 is
+ *   computed in place on `stream`; the others travel to their model's device and back with hipMemcpyPeerAsync on that
+ *   model's own stream (xGMI between the GPUs of a node), and `stream` waits for them: no host synchronisation.
+ *   bounds[0 .. nmodel] (optional, NULL: equal ray counts): share k = rays [bounds[k], bounds[k+1]), e.g. from
+ *   jur_multi_balance when the geometry is known on the host.  d_status (optional) is int[nmodel], one word per share. */
+int  jur_multi_balance(jur_model_t const *m, long nr, double const *const geom[7], int nparts, long *bounds);
+int  jur_models_set_atm(jur_model_t *const models[], int nmodel, atm_t const *atm);
+int  jur_formod_host_multi(jur_model_t *const models[], int nmodel, long nr, double const *const geom[7],
+                           double *rad, double *tau, double *const tp[3], int *np_out);
+int  jur_formod_device_multi(jur_model_t *const models[], int nmodel, long nr, long const *bounds, double const *d_geom,
+                             double *d_rad, double *d_tau, double *d_tp, int *d_np, int *d_status, void *stream);
+
 /* Retrieval support (reference kernel(), jurassic.c:812-857; state/measurement
  * vectors as atm2x/obs2y, :1491-1541): forward-difference Jacobian dy/dx of the
  * finite radiances with respect to the atmosphere values inside the
@@ -173,6 +197,11 @@ int  jur_model_reserve(jur_model_t *m, long nr);
  * chunk size (rays per kernel launch) it uses. */
 long jur_model_workspace_bytes(jur_model_t const *m);
 int  jur_model_chunk_rays(jur_model_t const *m);
+/* Bytes of device memory the model's tables hold (entries, bracket slopes, descriptors). */
+long jur_model_table_bytes(jur_model_t const *m);
+/* PCI bus id (text, e.g. "0000:0c:00.0"; len >= 16) and the free / total device memory of `device` right now: what a
+ * multi-GPU caller records and plans its workspace budget with. */
+int  jur_device_info(int device, char *pci_bus_id, int len, size_t *free_bytes, size_t *total_bytes);
 /* Tuning knobs: rays per chunk; whether rays are processed in order of their
  * geometric tangent altitude (default on; results do not depend on it). */
 int  jur_model_set_chunk_rays(jur_model_t *m, int rays);
@@ -196,6 +225,27 @@ int  jur_model_set_pencil(jur_model_t *m, long max_rays, int rays_per_group);
  * the channel count is a multiple of four: other group shapes were measured slower than one channel per workgroup.
  * Results do not depend on it (tests/test_parity_gpu.py compares the arrangements bit for bit). */
 void jur_tune_combine(int channels_per_group, int sync_segments, long min_lanes);
+
+/* Arithmetic of the emissivity-growth look-up, per model (process default: JUR_ARITH_FAST, or JUR_ARITH_EXACT when
+ * the environment has JUR_EGA_NO_RCP set).
+ *   JUR_ARITH_FAST   strictly increasing tables (every table that passes the reference's row rule) are interpolated
+ *                    through bracket slopes formed once per model, blended through reciprocal bracket widths, and the
+ *                    path transmittance is carried as 1 - eps: within ~1e-13 of the reference's divisions on
+ *                    transmittances, ~6e-12 relative on radiances (the contract is 1e-6), a seventh fewer instructions;
+ *   JUR_ARITH_EXACT  the reference's divisions operand for operand (jr_common.h:156-185, 237-268) -- what tables that
+ *                    are not strictly increasing get in either mode.  For difference quotients with steps so small
+ *                    that 1e-12 of a radiance matters (jur_kernel on mixing ratios that are zero: see there).
+ * The fused kernel and the batched kernels follow the same switch, so they stay bit-identical to each other. */
+enum { JUR_ARITH_FAST = 0, JUR_ARITH_EXACT = 1 };
+int  jur_model_set_arithmetic(jur_model_t *m, int mode);
+int  jur_model_arithmetic(jur_model_t const *m);
+
+/* Look-up kernel arrangement (experiment of round 4): nch in 2 .. 4 lets one lane walk up to nch
+ * channels of a gas whose tables stand on the same (p, T) grid (brackets and LOS row once per segment and group);
+ * nch < 2 (the default) keeps one (channel, gas) pair per workgroup, which is faster on every shape measured.
+ * Strictly increasing tables only; bit-identical results. */
+int  jur_model_set_ega_group(jur_model_t *m, int nch);
+int  jur_model_ega_group(jur_model_t const *m);   /* channels per lane of the next call (0: one pair per workgroup) */
 
 /* Frees the process-global state behind formod() / formod_GPU() / formod_pencil(): the lanes (streams, atmosphere,
  * workspaces, pinned images) and the emissivity tables loaded by the first call.  Upstream keeps its counterparts for

@@ -81,6 +81,8 @@ typedef struct {
   int max_pair_curves;          /* most curves any (gas, channel) pair has (LDS staging size)  */
   int strict_tables;            /* sorted, and p, T axes and (as stored, fp32) all curves strictly increasing:
                                    no bracket of the look-up has zero width                                     */
+  int fast_arith;               /* the look-up runs the strict-table arithmetic (JUR_ARITH_FAST on strict tables whose
+                                   descriptors fit the LDS staging); 0: the reference's divisions operand for operand */
   jur_item_t const *ega_items;  /* [ega_nitems] channel groups on a shared (p, T) grid, or NULL: one pair per workgroup */
   int ega_nitems;
   int ega_nch;                  /* channels of the largest item (1: nothing is shared)                           */
@@ -127,8 +129,8 @@ int jurk_fill_slopes(jur_ue_t const *ue, jur_sl_t *sl, long long n, void *stream
 /* order rays by their geometric tangent altitude: fills order[nr]; `tmp` is a
  * device scratch of jurk_sort_tmp_bytes(nr) bytes */
 long jurk_sort_tmp_bytes(long nr);
-int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, double const *d_geom, int *d_order, void *tmp,
-                   long tmp_bytes, void *stream);
+int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, double const *d_geom, long ld, int *d_order, void *tmp,
+                   long tmp_bytes, void *stream);   /* field k of ray r at d_geom[k * ld + r] */
 
 /* the whole path of small calls in one kernel, RB rays per workgroup (c->order is ignored: nothing is sorted) */
 long jurk_pencil_lds_bytes(jur_view_t const *v, int RB);
@@ -149,6 +151,21 @@ int jurk_kat_continua(jur_view_t const *v, int d, long n, double const *p, doubl
                       double const *u_h2o, double *out, void *stream);
 int jurk_kat_update(jur_view_t const *v, int d, long n, int what, double const *a, double const *b, double const *c, double *rad,
                     double *tau, double *src, void *stream);
+
+/* internals of a model that jur_multi.c needs (jur_model.c) */
+/* jur_formod_device on rays that are part of larger arrays: geometry field k at d_geom + k * ldg, tangent-point field k
+ * at d_tp + k * ldtp (jur_formod_device: ldg = ldtp = nr) */
+int jur_formod_device_ld(jur_model_t *m, long nr, double const *d_geom, long ldg, double *d_rad, double *d_tau, double *d_tp,
+                         long ldtp, int *d_np, int *d_status, void *stream);
+int jur_model_device(jur_model_t const *m);
+int jur_model_nd(jur_model_t const *m);
+void *jur_model_stream(jur_model_t const *m);
+int *jur_model_status_word(jur_model_t const *m);
+/* step sizes of the ray tracer and the altitude range of the atmosphere on the device (for cost estimates) */
+void jur_model_cost_params(jur_model_t const *m, double *rayds, double *raydz, double *zmin, double *zmax);
+/* device scratch of the model for nr rays laid out as jur_formod_host's image: geom[7][nr] | rad[nr][nd] | tau[nr][nd] |
+ * tp[3][nr] doubles, np[nr] ints */
+int jur_model_io(jur_model_t *m, long nr, double **d_io, int **d_io_np);
 
 /* host tables (jur_tables.c) */
 typedef struct {
@@ -189,8 +206,11 @@ typedef struct {
   jur_ue_t *ue;
 } jur_flat_t;
 int  jur_tables_flatten(jur_tables_t const *tb, jur_flat_t *out);
-/* channel groups on a shared (p, T) grid, at most nch channels each (malloc'ed; pairs without a table are in no item) */
-int  jur_flat_group_items(jur_flat_t const *f, int ng, int nd, int nch, jur_item_t **items, int *nitems, int *max_nch);
+/* channel groups on a shared (p, T) grid: the class of every pair, then items of at most nch channels (malloc'ed;
+ * pairs without a table are in no item) */
+int  jur_flat_grid_classes(jur_flat_t const *f, int ng, int nd, int *cls, unsigned char *all_curves);
+int  jur_group_items(int ng, int nd, int nch, int const *cls, unsigned char const *all_curves, long long const *pair_e0,
+                     jur_item_t **items, int *nitems, int *max_nch);
 void jur_flat_free(jur_flat_t *f);
 
 void jur_tables_cache_filename(char *out, size_t len, ctl_t const *ctl);

@@ -1908,12 +1908,12 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
         double tau_new;                                            // the gas's path transmittance after this segment
         if constexpr (WARM && QUAD) {
           unsigned br = st_br[e], ix = st_ix[4 * e + (lane & 3)];
-          if (v.strict_tables) tau_new = ega_eps_warm_quad<true>(v, pd, D, tau_path, t, u, p, br, ix);
+          if (v.fast_arith) tau_new = ega_eps_warm_quad<true>(v, pd, D, tau_path, t, u, p, br, ix);
           else tau_new = tau_path * ega_eps_warm_quad<false>(v, pd, D, tau_path, t, u, p, br, ix);
           st_br[e] = br; st_ix[4 * e + (lane & 3)] = ix;
         } else if constexpr (WARM) {
           unsigned br = st_br[e], ia = st_ix[4 * e], ib = st_ix[4 * e + 1];
-          if (v.strict_tables) tau_new = ega_eps_warm<false, true, true>(v, pd, D, tau_path, t, u, p, br, ia, ib);
+          if (v.fast_arith) tau_new = ega_eps_warm<false, true, true>(v, pd, D, tau_path, t, u, p, br, ia, ib);
           else tau_new = tau_path * ega_eps_warm<false, false>(v, pd, D, tau_path, t, u, p, br, ia, ib);
           st_br[e] = br; st_ix[4 * e] = ia; st_ix[4 * e + 1] = ib;
         } else tau_new = tau_path * ega_eps_exact<false>(v, pd, D, tau_path, t, u, p);
@@ -2039,14 +2039,14 @@ __global__ __launch_bounds__(256) void jur_slopes_kernel(long long n, jur_ue_t c
   }
 }
 
-__global__ __launch_bounds__(256) void jur_raykey_kernel(long nr, double const *__restrict__ geom,
+__global__ __launch_bounds__(256) void jur_raykey_kernel(long nr, long ld, double const *__restrict__ geom,
                                                          double const *__restrict__ atm_time, int atm_np, int by_profile,
                                                          unsigned long long *__restrict__ key, int *__restrict__ id) {
   long const r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nr) return;
   double xo[3], xv[3], e[3];
-  geo2cart(geom[1 * nr + r], geom[2 * nr + r], geom[3 * nr + r], xo);
-  geo2cart(geom[4 * nr + r], geom[5 * nr + r], geom[6 * nr + r], xv);
+  geo2cart(geom[1 * ld + r], geom[2 * ld + r], geom[3 * ld + r], xo);      // field k of ray r: geom[k * ld + r]
+  geo2cart(geom[4 * ld + r], geom[5 * ld + r], geom[6 * ld + r], xv);
   for (int i = 0; i < 3; i++) e[i] = xv[i] - xo[i];
   double const n = norm3(e);
   double h = norm3(xo) - JUR_RE;
@@ -2290,10 +2290,8 @@ static int launch_ega_group(jur_view_t const *v, jur_chunk_t const *c, hipStream
   static int const env_group = getenv("JUR_EGA_GROUP") ? atoi(getenv("JUR_EGA_GROUP")) : -1;      // A/B switches, read once
   static int const env_block = getenv("JUR_EGA_BLOCK") ? atoi(getenv("JUR_EGA_BLOCK")) : 0;
   static int const env_waves = getenv("JUR_EGA_WAVES") ? atoi(getenv("JUR_EGA_WAVES")) : 0;
-  if (!v->ega_items || v->ega_nitems <= 0 || v->ega_nch < 2 || !v->strict_tables || env_group == 0 || getenv("JUR_EGA_NO_RCP") ||
-      getenv("JUR_EGA_NO_LDS"))
-    return -1;
-  int const block = (env_block >= 64 && env_block <= 1024 && env_block % 64 == 0) ? env_block : 448;
+  if (!v->ega_items || v->ega_nitems <= 0 || v->ega_nch < 2 || !v->fast_arith || env_group == 0 || getenv("JUR_EGA_NO_LDS")) return -1;
+  int const block = (env_block >= 64 && env_block <= 1024 && env_block % 64 == 0) ? env_block : 256;
   int const waves = env_waves >= 6 && env_waves <= 8 ? env_waves : 7;
   size_t const lds = ega_group_lds_bytes(v->max_pair_curves, v->ega_nch, block);
   if (lds > 128 * 1024) return -1;
@@ -2325,7 +2323,7 @@ extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *
   // (+ 8 B x the same counts for the reciprocal bracket widths of strictly increasing tables)
   size_t const lds = (sizeof(jur_lvl_t) + 8) * JUR_TBLNP + (sizeof(jur_crv_t) + 8) * (size_t)v->max_pair_curves;
   bool const use_lds = v->max_pair_curves > 0 && lds <= 48 * 1024 && !getenv("JUR_EGA_NO_LDS");
-  bool const rcpb = use_lds && v->strict_tables && !getenv("JUR_EGA_NO_RCP");
+  bool const rcpb = use_lds && v->fast_arith;
   if (v->sorted_tables) {
     if (rcpb) hipLaunchKernelGGL((jur_ega_kernel<true, true, true>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
     else if (use_lds) hipLaunchKernelGGL((jur_ega_kernel<true, true, false>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
@@ -2406,7 +2404,7 @@ extern "C" long jurk_sort_tmp_bytes(long nr) {
   return (long)(2 * align_up(8 * (size_t)nr) + align_up(4 * (size_t)nr) + align_up(cub) + 256);
 }
 
-extern "C" int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, double const *d_geom, int *d_order, void *tmp,
+extern "C" int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, double const *d_geom, long ld, int *d_order, void *tmp,
                               long tmp_bytes, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   size_t const seg8 = align_up(8 * (size_t)nr), seg4 = align_up(4 * (size_t)nr);
@@ -2416,7 +2414,7 @@ extern "C" int jurk_sort_rays(jur_view_t const *v, int by_profile, long nr, doub
   void *cub_tmp = base + 2 * seg8 + seg4;
   size_t cub_bytes = (size_t)tmp_bytes - 2 * seg8 - seg4;
   int const block = 256;
-  hipLaunchKernelGGL(jur_raykey_kernel, dim3((unsigned)((nr + block - 1) / block)), dim3(block), 0, s, nr, d_geom,
+  hipLaunchKernelGGL(jur_raykey_kernel, dim3((unsigned)((nr + block - 1) / block)), dim3(block), 0, s, nr, ld, d_geom,
                      v->atm_time, v->atm_np, by_profile, key_in, id_in);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;

@@ -33,9 +33,14 @@ struct jur_model {
   long table_bytes;
   /* device allocations owned by the model */
   void *d_chan, *d_sr, *d_pair, *d_pair_e0, *d_lvl, *d_crv, *d_ue, *d_sl, *d_items;
+  int arith;                    /* JUR_ARITH_*                                   */
+  int *grid_cls;                /* [ng*nd] grid class of every pair (strict tables), see jur_model_set_ega_group */
+  unsigned char *grid_all;
+  long long *h_pair_e0;
   void *d_atm;                  /* one slab for the compact atmosphere           */
   int atm_cap;
   int atm_slices;               /* distinct time stamps in the atmosphere        */
+  double atm_zmin, atm_zmax;    /* altitude range of the atmosphere on the device */
   /* per-call workspace */
   int chunk_rays;               /* R                                             */
   int nfield;
@@ -195,16 +200,15 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
       rc = JUR_EHIP;
     }
   }
-  if (!rc && fl.strict) {       /* channels of a gas whose tables stand on one (p, T) grid: jur_ega_group_kernel walks them together */
-    jur_item_t *items = NULL;
-    int nitems = 0, max_nch = 0, want = JUR_EGA_NCH;
-    if (getenv("JUR_EGA_GROUP") && atoi(getenv("JUR_EGA_GROUP")) >= 1) want = atoi(getenv("JUR_EGA_GROUP"));
-    rc = jur_flat_group_items(&fl, ctl->ng, ctl->nd, want, &items, &nitems, &max_nch);
-    if (!rc && max_nch >= 2) {
-      rc = upload(&m->d_items, items, sizeof(jur_item_t) * nitems);
-      if (!rc) { v->ega_items = (jur_item_t const *)m->d_items; v->ega_nitems = nitems; v->ega_nch = max_nch; }
+  if (!rc && fl.strict && npair > 0) {   /* which channels of a gas stand on one (p, T) grid: jur_model_set_ega_group */
+    m->grid_cls = (int *)malloc(sizeof(int) * npair);
+    m->grid_all = (unsigned char *)malloc(npair);
+    m->h_pair_e0 = (long long *)malloc(sizeof(long long) * npair);
+    if (!m->grid_cls || !m->grid_all || !m->h_pair_e0) rc = JUR_ENOMEM;
+    else {
+      memcpy(m->h_pair_e0, fl.pair_e0, sizeof(long long) * npair);
+      rc = jur_flat_grid_classes(&fl, ctl->ng, ctl->nd, m->grid_cls, m->grid_all);
     }
-    free(items);
   }
   v->sorted_tables = fl.sorted;
   v->strict_tables = fl.strict;
@@ -220,6 +224,12 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   v->crv = (jur_crv_t const *)m->d_crv;
   v->ue = (jur_ue_t const *)m->d_ue;
   v->sl = (jur_sl_t const *)m->d_sl;
+  if ((rc = jur_model_set_arithmetic(m, getenv("JUR_EGA_NO_RCP") ? JUR_ARITH_EXACT : JUR_ARITH_FAST))) { jur_model_destroy(m); return rc; }
+  /* measured slower than one pair per workgroup: only on request */
+  if (getenv("JUR_EGA_GROUP") && atoi(getenv("JUR_EGA_GROUP")) >= 2 && (rc = jur_model_set_ega_group(m, atoi(getenv("JUR_EGA_GROUP"))))) {
+    jur_model_destroy(m);
+    return rc;
+  }
 
   m->nfield = JUR_F_K + v->nw + v->ng;
   m->chunk_rays = 1 << 21;      /* upper bound; the workspace budget sets the real size (1.4 M rays for 96 KB per ray).
@@ -241,6 +251,46 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   *out = m;
   return JUR_OK;
 }
+
+/* JUR_ARITH_FAST (default): on strictly increasing tables whose descriptors fit the LDS staging the look-up uses bracket
+ * slopes, reciprocal bracket widths and carries the path transmittance as 1 - eps (~1e-13 from the reference's
+ * divisions); JUR_ARITH_EXACT: the reference's divisions operand for operand (what every other table gets anyway).
+ * Takes effect with the next call; calls in flight are the caller's to wait for. */
+int jur_model_set_arithmetic(jur_model_t *m, int mode) {
+  if (mode != JUR_ARITH_FAST && mode != JUR_ARITH_EXACT) { jur_set_error("set_arithmetic: JUR_ARITH_FAST or JUR_ARITH_EXACT"); return JUR_EINVAL; }
+  jur_view_t *v = &m->view;
+  /* (the staging size of jurk_launch_ega: 24 B per level and curve of the largest pair, at most 48 KB) */
+  int const lds_ok = v->max_pair_curves > 0 && 24L * JUR_TBLNP + 24L * v->max_pair_curves <= 48 * 1024 && !getenv("JUR_EGA_NO_LDS");
+  m->arith = mode;
+  v->fast_arith = (mode == JUR_ARITH_FAST) && v->strict_tables && v->sl && lds_ok;
+  return JUR_OK;
+}
+int jur_model_arithmetic(jur_model_t const *m) { return m->arith; }
+
+/* Channels of a gas whose tables stand on one (p, T) grid walked together by one lane (jur_ega_group_kernel), at most
+ * nch (2 .. JUR_EGA_NCH) per lane; nch < 2: one (channel, gas) pair per workgroup (jur_ega_kernel, the default).
+ * Strict tables only; results are the same doubles either way. */
+int jur_model_set_ega_group(jur_model_t *m, int nch) {
+  if (m->shared_tables) { jur_set_error("set_ega_group: a lane shares its tables with another model"); return JUR_EINVAL; }
+  HIPCHK(hipSetDevice(m->device));
+  jur_view_t *v = &m->view;
+  if (m->have_done) HIPCHK(hipEventSynchronize(m->ev_done));      /* launches in flight still read the old items */
+  if (m->d_items) { (void)hipFree(m->d_items); m->d_items = NULL; }
+  v->ega_items = NULL; v->ega_nitems = 0; v->ega_nch = 0;
+  if (nch < 2 || !v->strict_tables || !m->grid_cls) return JUR_OK;      /* (runs only while fast_arith is on) */
+  jur_item_t *items = NULL;
+  int nitems = 0, max_nch = 0;
+  int rc = jur_group_items(v->ng, v->nd, nch, m->grid_cls, m->grid_all, m->h_pair_e0, &items, &nitems, &max_nch);
+  if (!rc && max_nch >= 2) {
+    rc = upload(&m->d_items, items, sizeof(jur_item_t) * nitems);
+    if (!rc) { v->ega_items = (jur_item_t const *)m->d_items; v->ega_nitems = nitems; v->ega_nch = max_nch; }
+  }
+  free(items);
+  return rc;
+}
+
+/* channels per lane the next call's look-up kernel walks (0: one pair per workgroup) */
+int jur_model_ega_group(jur_model_t const *m) { return (m->view.ega_items && m->view.fast_arith) ? m->view.ega_nch : 0; }
 
 int jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device) {
   *out = NULL;
@@ -285,6 +335,7 @@ void jur_model_destroy(jur_model_t *m) {
   if (m->h_pkg) (void)hipHostFree(m->h_pkg);
   if (m->h_status) (void)hipHostFree(m->h_status);
   free(m->h_atm);
+  if (!m->shared_tables) { free(m->grid_cls); free(m->grid_all); free(m->h_pair_e0); }
   if (m->stream) (void)hipStreamDestroy(m->stream);
   if (m->stream2) (void)hipStreamDestroy(m->stream2);
   if (m->ev_mask) (void)hipEventDestroy(m->ev_mask);
@@ -380,6 +431,8 @@ static int upload_atm_rows(jur_model_t *m, double const *h, long n) {
   HIPCHK(hipStreamSynchronize(m->stream));
   double const *time = h, *z = h + (size_t)n;
   m->atm_slices = 1;
+  m->atm_zmin = m->atm_zmax = z[0];
+  for (long i = 1; i < n; i++) { if (z[i] < m->atm_zmin) m->atm_zmin = z[i]; if (z[i] > m->atm_zmax) m->atm_zmax = z[i]; }
   v->atm_sorted = 1;
   v->atm_maxslice = 1;
   for (long i = 1, dir = 0, run = 1; i < n; i++) {
@@ -505,6 +558,28 @@ static int ensure_workspace(jur_model_t *m, long nr) {
 }
 
 long jur_model_workspace_bytes(jur_model_t const *m) { return m->los_bytes; }
+long jur_model_table_bytes(jur_model_t const *m) { return m->table_bytes; }
+
+/* What a caller that plans its memory wants to know about a device before it allocates: PCI bus id (text), free and
+ * total bytes right now. */
+int jur_device_info(int device, char *pci_bus_id, int len, size_t *free_bytes, size_t *total_bytes) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { jur_set_error("device %d not available", device); return JUR_ENODEV; }
+  HIPCHK(hipSetDevice(device));
+  if (pci_bus_id && len > 0) HIPCHK(hipDeviceGetPCIBusId(pci_bus_id, len, device));
+  size_t f = 0, t = 0;
+  HIPCHK(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return JUR_OK;
+}
+int jur_model_device(jur_model_t const *m) { return m->device; }
+int jur_model_nd(jur_model_t const *m) { return m->view.nd; }
+void *jur_model_stream(jur_model_t const *m) { return (void *)m->stream; }
+int *jur_model_status_word(jur_model_t const *m) { return m->d_status; }
+void jur_model_cost_params(jur_model_t const *m, double *rayds, double *raydz, double *zmin, double *zmax) {
+  *rayds = m->view.rayds; *raydz = m->view.raydz; *zmin = m->atm_zmin; *zmax = m->atm_zmax;
+}
 int jur_model_chunk_rays(jur_model_t const *m) { return m->chunk_rays; }
 
 int jur_model_set_sort_rays(jur_model_t *m, int on) { m->sort_rays = on ? 1 : 0; return JUR_OK; }
@@ -641,6 +716,11 @@ static int record_done(jur_model_t *m, hipStream_t s) {
 
 int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_rad, double *d_tau, double *d_tp,
                       int *d_np, int *d_status, void *stream) {
+  return jur_formod_device_ld(m, nr, d_geom, nr, d_rad, d_tau, d_tp, nr, d_np, d_status, stream);
+}
+
+int jur_formod_device_ld(jur_model_t *m, long nr, double const *d_geom, long ldg, double *d_rad, double *d_tau, double *d_tp,
+                         long ldtp, int *d_np, int *d_status, void *stream) {
   if (!m || nr < 0) { jur_set_error("formod_device: bad arguments"); return JUR_EINVAL; }
   if (nr == 0) return JUR_OK;
   if (nr > 0x7fffffffL) { jur_set_error("formod_device: at most 2^31-1 rays per call"); return JUR_EINVAL; }
@@ -653,8 +733,8 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     jur_chunk_t c;
     memset(&c, 0, sizeof c);
     c.n = (int)nr;
-    for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * nr;
-    for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * nr;
+    for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * ldg;
+    for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * ldtp;
     c.rad = d_rad;
     c.tau = d_tau;
     c.np_out = d_np;
@@ -679,7 +759,7 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     if (rc) return rc;
     /* group by atmosphere slice when every slice is used by many rays */
     int const by_profile = m->atm_slices > 1 && nr >= 1024L * m->atm_slices;
-    int const e = jurk_sort_rays(&m->view, by_profile, nr, d_geom, m->d_order, m->d_sort_tmp, m->sort_tmp_bytes, s);
+    int const e = jurk_sort_rays(&m->view, by_profile, nr, d_geom, ldg, m->d_order, m->d_sort_tmp, m->sort_tmp_bytes, s);
     if (e) { jur_set_error("ray sort failed: %s", hipGetErrorString((hipError_t)e)); return JUR_EHIP; }
     order = m->d_order;
   }
@@ -697,8 +777,8 @@ int jur_formod_device(jur_model_t *m, long nr, double const *d_geom, double *d_r
     long const nt = (nr - t0 < Rt) ? nr - t0 : Rt;
     c.stride = (int)Rt;
     c.stride_eps = (int)R;
-    for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * nr;
-    for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * nr;
+    for (int k = 0; k < 7; k++) c.geom[k] = d_geom + (size_t)k * ldg;
+    for (int k = 0; k < 3; k++) c.tp[k] = d_tp + (size_t)k * ldtp;
     c.rad = d_rad;
     c.tau = d_tau;
     c.np_out = d_np;
@@ -806,6 +886,14 @@ static int ensure_io(jur_model_t *m, long nr, int want_host) {
     HIPCHK(hipHostMalloc((void **)&m->h_io, sizeof(double) * nval + sizeof(int) * (size_t)nr, hipHostMallocDefault));
     m->h_io_cap = nr;
   }
+  return JUR_OK;
+}
+
+int jur_model_io(jur_model_t *m, long nr, double **d_io, int **d_io_np) {
+  HIPCHK(hipSetDevice(m->device));
+  int const rc = ensure_io(m, nr, 0);
+  if (rc) return rc;
+  *d_io = m->d_io; *d_io_np = m->d_io_np;
   return JUR_OK;
 }
 

@@ -550,41 +550,58 @@ static int same_grid(jur_flat_t const *f, long a, long b) {
   return 1;
 }
 
-int jur_flat_group_items(jur_flat_t const *f, int ng, int nd, int nch, jur_item_t **items, int *nitems, int *max_nch) {
+/* Grid class of every pair (pairs of one gas with equal class stand on the same (p, T) grid; -1: no table) and
+ * whether all its curves have at least two entries. */
+int jur_flat_grid_classes(jur_flat_t const *f, int ng, int nd, int *cls, unsigned char *all_curves) {
+  long *rep = (long *)malloc(sizeof(long) * (nd > 0 ? nd : 1));
+  if (!rep) return JUR_ENOMEM;
+  for (int g = 0; g < ng; g++) {
+    int nclass = 0;
+    for (int d = 0; d < nd; d++) {
+      long const i = (long)g * nd + d;
+      cls[i] = -1; all_curves[i] = 1;
+      if (f->pair[i].a < 2) continue;            /* no table: the look-up answers 1, nothing to do */
+      int c = 0;
+      while (c < nclass && !same_grid(f, rep[c], i)) c++;
+      if (c == nclass) rep[nclass++] = i;
+      cls[i] = c;
+      jur_lvl_t const *lv = f->lvl + f->pair[i].b;
+      for (int ip = 0; ip < f->pair[i].a; ip++)
+        for (int k = 0; k < lv[ip].nt; k++)
+          if (f->crv[lv[ip].c0 + k].nu < 2) all_curves[i] = 0;
+    }
+  }
+  free(rep);
+  return JUR_OK;
+}
+
+/* Items of at most nch channels each from the classes: per gas, the channels of a class in ascending order. */
+int jur_group_items(int ng, int nd, int nch, int const *cls, unsigned char const *all_curves, long long const *pair_e0,
+                    jur_item_t **items, int *nitems, int *max_nch) {
   *items = NULL; *nitems = 0; *max_nch = 0;
   if (nch < 1) nch = 1;
   if (nch > JUR_EGA_NCH) nch = JUR_EGA_NCH;
   long const npair = (long)ng * nd;
   jur_item_t *out = (jur_item_t *)calloc(npair > 0 ? npair : 1, sizeof(jur_item_t));
-  /* per gas: the grid classes met so far, each with the representative pair and its open item */
-  long *rep = (long *)malloc(sizeof(long) * (nd > 0 ? nd : 1));
-  int *open = (int *)malloc(sizeof(int) * (nd > 0 ? nd : 1));
-  if (!out || !rep || !open) { free(out); free(rep); free(open); return JUR_ENOMEM; }
+  int *open = (int *)malloc(sizeof(int) * (nd > 0 ? nd : 1));      /* per class of the gas: its unfinished item */
+  if (!out || !open) { free(out); free(open); return JUR_ENOMEM; }
   int n = 0;
   for (int g = 0; g < ng; g++) {
-    int nclass = 0;
+    for (int c = 0; c < nd; c++) open[c] = -1;
     for (int d = 0; d < nd; d++) {
       long const i = (long)g * nd + d;
-      if (f->pair[i].a < 2) continue;            /* no table: the look-up answers 1, nothing to do */
-      int c = 0;
-      while (c < nclass && !same_grid(f, rep[c], i)) c++;
-      if (c == nclass) { rep[c] = i; open[c] = -1; nclass++; }
+      int const c = cls[i];
+      if (c < 0) continue;
       if (open[c] < 0) { open[c] = n++; out[open[c]].g = g; out[open[c]].nch = 0; out[open[c]].flags = 1; }
       jur_item_t *it = &out[open[c]];
-      {  /* curves shorter than two entries make the look-up answer "no change": the kernel tests for them only
-            where an item has any */
-        jur_lvl_t const *lv = f->lvl + f->pair[i].b;
-        for (int ip = 0; ip < f->pair[i].a; ip++)
-          for (int k = 0; k < lv[ip].nt; k++)
-            if (f->crv[lv[ip].c0 + k].nu < 2) it->flags &= ~1;
-      }
-      it->e0[it->nch] = f->pair_e0[i];
+      if (!all_curves[i]) it->flags &= ~1;       /* the kernel tests for short curves only where an item has any */
+      it->e0[it->nch] = pair_e0[i];
       it->d[it->nch++] = d;
       if (it->nch > *max_nch) *max_nch = it->nch;
       if (it->nch == nch) open[c] = -1;
     }
   }
-  free(rep); free(open);
+  free(open);
   *items = out; *nitems = n;
   return JUR_OK;
 }

@@ -62,6 +62,9 @@ def lib():
         L.jur_model_reserve.argtypes = [C.c_void_p, C.c_long]
         L.jur_model_workspace_bytes.restype = C.c_long
         L.jur_model_workspace_bytes.argtypes = [C.c_void_p]
+        L.jur_model_table_bytes.restype = C.c_long
+        L.jur_model_table_bytes.argtypes = [C.c_void_p]
+        L.jur_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.jur_model_chunk_rays.argtypes = [C.c_void_p]
         L.jur_model_set_chunk_rays.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_set_sort_rays.argtypes = [C.c_void_p, C.c_int]
@@ -71,6 +74,14 @@ def lib():
         L.jur_model_last_kernel_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
         L.jur_model_last_pencil_ms.argtypes = [C.c_void_p, dp, C.POINTER(C.c_long)]
         L.jur_model_set_pencil.argtypes = [C.c_void_p, C.c_long, C.c_int]
+        L.jur_model_set_arithmetic.argtypes = [C.c_void_p, C.c_int]
+        L.jur_model_arithmetic.argtypes = [C.c_void_p]
+        L.jur_model_set_ega_group.argtypes = [C.c_void_p, C.c_int]
+        L.jur_model_ega_group.argtypes = [C.c_void_p]
+        L.jur_multi_balance.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), C.c_int, C.POINTER(C.c_long)]
+        L.jur_models_set_atm.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+        L.jur_formod_host_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.POINTER(dp), dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
+        L.jur_formod_device_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.POINTER(C.c_long)] + [C.c_void_p] * 7
         L.jur_tune_combine.argtypes = [C.c_int, C.c_int, C.c_long]
         L.jur_tune_combine.restype = None
         L.jur_state_size.restype = C.c_size_t
@@ -233,6 +244,15 @@ class Model:
         """Calls of up to max_rays rays run as one fused kernel (0: never)."""
         _chk(lib().jur_model_set_pencil(self.h, max_rays, rays_per_group))
 
+    def set_arithmetic(self, mode):
+        """ARITH_FAST (default) or ARITH_EXACT: the look-up's arithmetic on strictly increasing tables."""
+        _chk(lib().jur_model_set_arithmetic(self.h, int(mode)))
+
+    def set_ega_group(self, nch):
+        """nch in 2..4: the channel-group look-up kernel (round-4 experiment); < 2: one pair per workgroup (default)."""
+        _chk(lib().jur_model_set_ega_group(self.h, int(nch)))
+        return lib().jur_model_ega_group(self.h)       # channels per lane the next call will walk (0: default kernel)
+
     def set_trace_multiple(self, mult):
         _chk(lib().jur_model_set_trace_multiple(self.h, mult))
 
@@ -331,6 +351,59 @@ class Model:
 
     def workspace_bytes(self):
         return lib().jur_model_workspace_bytes(self.h)
+
+    def table_bytes(self):
+        return lib().jur_model_table_bytes(self.h)
+
+
+ARITH_FAST, ARITH_EXACT = 0, 1
+
+
+def device_info(device):
+    """-> dict(pci_bus_id, free, total) of a HIP device (jur_device_info)."""
+    buf = C.create_string_buffer(64)
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    _chk(lib().jur_device_info(device, buf, 64, C.byref(f), C.byref(t)))
+    return dict(pci_bus_id=buf.value.decode(), free=int(f.value), total=int(t.value))
+
+
+def _handles(models):
+    return (C.c_void_p * len(models))(*[m.h for m in models])
+
+
+def multi_balance(model, geom, nparts):
+    """Boundaries of nparts contiguous ray ranges with equal estimated LOS points (jur_multi_balance)."""
+    g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
+    garr = (dp * 7)(*[_p(g[k]) for k in range(7)])
+    b = (C.c_long * (nparts + 1))()
+    _chk(lib().jur_multi_balance(model.h, g.shape[1], garr, nparts, b))
+    return list(b)
+
+
+def models_set_atm(models, atm):
+    _chk(lib().jur_models_set_atm(_handles(models), len(models), C.byref(atm)))
+
+
+def formod_host_multi(models, geom, rad_in=None):
+    """jur_formod_host_multi: the rays of one call dealt to several models (one per device).  Same result dict as
+    Model.formod_host."""
+    g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
+    nr, nd = g.shape[1], models[0].nd
+    rad = np.zeros((nr, nd)) if rad_in is None else np.ascontiguousarray(rad_in, dtype=np.float64).copy()
+    tau = np.zeros((nr, nd))
+    tp = np.zeros((3, nr))
+    npts = np.zeros(nr, dtype=np.int32)
+    garr = (dp * 7)(*[_p(g[k]) for k in range(7)])
+    tarr = (dp * 3)(*[_p(tp[k]) for k in range(3)])
+    _chk(lib().jur_formod_host_multi(_handles(models), len(models), nr, garr, _p(rad), _p(tau), tarr,
+                                     npts.ctypes.data_as(C.POINTER(C.c_int))))
+    return dict(rad=rad, tau=tau, tp=np.ascontiguousarray(tp.T), np=npts)
+
+
+def formod_device_multi(models, nr, d_geom, d_rad, d_tau, d_tp, d_np=0, d_status=0, stream=0, bounds=None):
+    """jur_formod_device_multi: raw device addresses on models[0]'s GPU; bounds: nmodel + 1 ray indices or None."""
+    b = None if bounds is None else (C.c_long * (len(models) + 1))(*bounds)
+    _chk(lib().jur_formod_device_multi(_handles(models), len(models), nr, b, d_geom, d_rad, d_tau, d_tp, d_np, d_status, stream))
 
 
 def formod(ctl, atm, obs):

@@ -68,7 +68,7 @@ def test_ray_ranges_partition_exactly():
 
 def _bench(*argv, env=None):
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    e.update(OMP_NUM_THREADS="2", **(env or {}))
+    e.update({"OMP_NUM_THREADS": "2", **(env or {})})
     return subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), *argv], capture_output=True, text=True,
                           env=e, timeout=900)
 
@@ -129,6 +129,27 @@ def test_bench_airs_workload_starts_the_wide_build_and_shards_by_index():
     doc = json.loads(out.stdout.strip())
     assert doc["n_gpus"] == 1 and doc["config"]["channels"] == 2378 and doc["config"]["rays_total"] == 40
     assert "1 of the 8 GPU shares" in doc["config"]["workload"]
+
+
+def test_bench_eight_ranks_ragged_dry_run():
+    """First contact with an 8-GPU node should be boring: `bench.py --gpus 8 --dry-run` through its own launcher for
+    both sharded workloads with ray counts that do not divide by eight -- eight children, eight contiguous ranges that
+    tile the set, the gather verified on sampled rows (shard boundaries included), the backend recorded per rank."""
+    for workload, rays, nd in (("limb_1e7_sharded", 100_003, 4), ("airs_2378_sharded", 1_003, 2378)):
+        out = _bench("--gpus", "8", "--workload", workload, "--steps", "1", "--warmup", "1", "--rays", str(rays), "--dry-run",
+                     env=dict(OMP_NUM_THREADS="1"))
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        doc = json.loads(out.stdout.strip())
+        assert doc["n_gpus"] == 8 and doc["dry_run"] is True and doc["config"]["channels"] == nd
+        counts = doc["config"]["rays_per_gpu"]
+        assert len(counts) == 8 and sum(counts) == rays and max(counts) - min(counts) == 1
+        kids = doc["launcher"]["children"]
+        assert [k["rank"] for k in kids] == list(range(8)) and len({k["pid"] for k in kids}) == 8
+        assert kids[0]["rays"][0] == 0 and kids[-1]["rays"][1] == rays
+        assert all(a["rays"][1] == b["rays"][0] for a, b in zip(kids, kids[1:]))
+        assert all(k["backend"] == "gloo" for k in kids)          # (on the GPUs: "nccl", which is RCCL on ROCm)
+        assert doc["gather_check"]["differing_values"] == 0
+        assert doc["scaling"] == ("strong" if workload.startswith("limb") else "weak")
 
 
 def test_geometry_is_index_addressable():

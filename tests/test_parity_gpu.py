@@ -712,11 +712,13 @@ def _retrieval_case(**kw):
     return case
 
 
+@pytest.mark.parametrize("arith", ["fast", "exact"])
 @pytest.mark.parametrize("kw", [dict(), dict(hydz=10.0)])
-def test_jacobian_matches_reference_kernel(hip, oracle, kw):
+def test_jacobian_matches_reference_kernel(hip, oracle, kw, arith):
     """jur_kernel (one batched call over n+1 stacked atmospheres) against the restated
-    kernel() loop of n+1 formod calls (jurassic.c:812-857).  Columns are difference quotients
-    (y1-y0)/h: compared relative to the largest entry of each column."""
+    kernel() loop of n+1 formod calls (jurassic.c:812-857), under both arithmetics of the look-up
+    (jur_model_set_arithmetic).  Columns are difference quotients (y1-y0)/h: compared relative to the largest entry of
+    each column."""
     case = _retrieval_case(**kw)
     obs_ref = _obs_from_geom(case.geom, 2)
     obs = _obs_from_geom(case.geom, 2)
@@ -724,6 +726,7 @@ def test_jacobian_matches_reference_kernel(hip, oracle, kw):
         o.rad[5][1] = float("nan")                        # a masked measurement drops its row
     k_ref = oracle.kernel(case.ctl, case.atm, obs_ref, case.oracle_tables(oracle))
     model = hip.Model(case.ctl, case.lib_tables())
+    model.set_arithmetic(hip.ARITH_EXACT if arith == "exact" else hip.ARITH_FAST)
     model.set_atm(case.atm)
     k = model.kernel(case.atm, obs)
     assert k.shape == k_ref.shape == (66 * 2 - 1, 6 + 31 + 21 + 11)
@@ -738,6 +741,58 @@ def test_jacobian_matches_reference_kernel(hip, oracle, kw):
     # the model is left with the caller's atmosphere
     again = model.formod_host(case.geom)
     assert common.rel_err(again["rad"][fin], b[fin]).max() < RTOL
+    model.close()
+
+
+def test_jacobian_columns_are_as_near_the_derivative_as_the_reference_ones(hip, oracle):
+    """Difference quotients divide the rounding noise of y by h.  For optically thin rays the ALGORITHM forms a segment's
+    emissivity as 1 - (1 - 1e-9): y is good to ~1e-12 relative only, in the reference as here, and implementations that
+    round differently disagree by that much per column whatever the look-up's arithmetic (tools/bench_jacobian.py:
+    profiles/r04_jacobian_limb_example.json has all 728 columns of the limb example).  The yardstick is a central
+    difference of the ORACLE with four times the reference's step (noise / 5.7, third-order truncation): per column, the
+    GPU's forward differences -- both arithmetics -- must lie no further from it than the oracle's own forward
+    differences do, up to 0.2 % of the column's norm.  Trace-gas columns at high altitude, where h is smallest, included."""
+    import copy
+    case = common.limb_case()
+    c = case.ctl
+    c.retp_zmin, c.retp_zmax, c.rett_zmin, c.rett_zmax = 30.0, 34.0, 30.0, 34.0
+    for g in range(c.ng):
+        c.retq_zmin[g], c.retq_zmax[g] = -999.0, -999.0
+    c.retq_zmin[1], c.retq_zmax[1] = 60.0, 90.0          # H2O at the top: mixing ratios of 1e-6 .. 1e-7, h = 1 % of that
+    c.retq_zmin[3], c.retq_zmax[3] = 20.0, 30.0          # F11
+    tb = case.oracle_tables(oracle)
+    obs_ref = _obs_from_geom(case.geom, 2)
+    k_ref = oracle.kernel(c, case.atm, obs_ref, tb)
+    n0 = case.atm.np
+    z = np.ctypeslib.as_array(case.atm.z)[:n0]
+    cols = ([("p", i) for i in range(n0) if 30 <= z[i] <= 34] + [("t", i) for i in range(n0) if 30 <= z[i] <= 34] +
+            [(1, i) for i in range(n0) if 60 <= z[i] <= 90] + [(3, i) for i in range(n0) if 20 <= z[i] <= 30])
+    assert len(cols) == k_ref.shape[1]
+
+    def field(a, kind):
+        return (np.ctypeslib.as_array(a.p) if kind == "p" else np.ctypeslib.as_array(a.t) if kind == "t"
+                else np.ctypeslib.as_array(a.q)[kind])
+    k_c = np.zeros_like(k_ref)
+    for j, (kind, lev) in enumerate(cols):
+        x0 = field(case.atm, kind)[lev]
+        h = max(abs(0.01 * x0), 1e-7) if kind == "p" else 1.0 if kind == "t" else max(abs(0.01 * x0), 1e-15)   # jurassic.c:831-837
+        y = []
+        for sign in (+1, -1):
+            a = copy.deepcopy(case.atm)
+            field(a, kind)[lev] = x0 + sign * 4 * h
+            y.append(oracle.formod_rays(c, a, tb, case.geom)["rad"].ravel())
+        k_c[:, j] = (y[0] - y[1]) / (8 * h)
+    scale = np.linalg.norm(k_c, axis=0)
+    d_ref = np.linalg.norm(k_ref - k_c, axis=0)
+    model = hip.Model(c, case.lib_tables())
+    model.set_atm(case.atm)
+    for mode in (hip.ARITH_FAST, hip.ARITH_EXACT):
+        model.set_arithmetic(mode)
+        k = model.kernel(case.atm, _obs_from_geom(case.geom, 2))
+        excess = (np.linalg.norm(k - k_c, axis=0) - d_ref) / scale
+        print("mode %d: columns further from the central differences than the oracle's %d of %d, worst excess %.2e of the "
+              "column norm (oracle's own distance: up to %.2e)" % (mode, np.count_nonzero(excess > 0), len(cols), excess.max(), (d_ref / scale).max()))
+        assert excess.max() < 2e-3
     model.close()
 
 
