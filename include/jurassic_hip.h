@@ -208,6 +208,14 @@ int  jur_model_set_chunk_rays(jur_model_t *m, int rays);
 int  jur_model_set_sort_rays(jur_model_t *m, int on);
 /* Rays per ray-tracing launch as a multiple of the rays per integration launch (default 1). */
 int  jur_model_set_trace_multiple(jur_model_t *m, int mult);
+/* Calls whose rays do not fit the workspace at JUR_NLOS points per ray (several integration launches) lay the
+ * transmittance tiles out by the path lengths that occur (default on): all rays are traced first, the longest path of
+ * every tile of 64 sorted rays comes back to the host -- ONE wait inside such a call; calls that fit in one launch, and
+ * calls being captured into a graph, never wait -- and consecutive tiles are packed into launches of equal size.
+ * Nadir rays use 182 of the 400 points: 2.2 x the rays per launch.  Same results bit for bit.
+ * jur_model_last_launches: integration launches (jur_ega_kernel / jur_combine_kernel pairs) of the last batched call. */
+int  jur_model_set_compact_workspace(jur_model_t *m, int on);
+long jur_model_last_launches(jur_model_t const *m);
 /* Upper bound of the per-call device workspace (LOS state + per-segment gas
  * transmittances); the rays-per-chunk shrink to fit.  Default 128 GiB of the 288 GB. */
 int  jur_model_set_workspace_budget(jur_model_t *m, long bytes);

@@ -113,6 +113,8 @@ typedef struct {
   double *tsurf;                /* [n]                                          */
   double *los;                  /* tiles of 64 slots: [slot / 64][JUR_NLOS][nfield][64]  */
   double *eps;                  /* path transmittances, tiles of 64 slots: [slot / 64][JUR_NLOS][nd*ng][64] */
+  int const *eps_off;           /* [tiles of the chunk] first point slot of every tile in eps when the tiles are laid out
+                                   by their longest path instead of JUR_NLOS points each; NULL: tile * JUR_NLOS       */
   int *status;                  /* device flag: bit0 = NLOS overflow            */
 } jur_chunk_t;
 
@@ -121,6 +123,7 @@ int jurk_prepare_atm(jur_view_t const *v, double *d_pslope, void *stream);   /* 
 int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, void *stream);
+int jurk_tile_max(int n, int const *d_np, int *d_tile_np, void *stream);   /* longest path per tile of 64 slots */
 void jurk_tune_combine(int group, int sync, long min_lanes);
 /* Curtis-Godson columns of the traced chunk: outputs [ray][gas][JUR_NLOS], indexed by ray id */
 int jurk_launch_cg(jur_view_t const *v, jur_chunk_t const *c, double *cgp, double *cgt, double *cgu, void *stream);

@@ -594,6 +594,11 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
 // life lies within NLOS x nfield x 512 B (2 MB for ten fields): a handful of pages per wavefront, where the round-1/2
 // layout [field][point][ray] put every field of every point on a page of its own (rows 8 MB apart for 1e6 rays).
 __device__ __forceinline__ size_t los_tile_doubles(int nfield) { return (size_t)NLOS * nfield * 64; }
+// First point slot of a tile in the transmittance workspace: tiles of NLOS points each, or -- when the call has been
+// laid out by the path lengths that occur (jur_model.c: compact chunks) -- the prefix sum of the tiles' longest paths.
+__device__ __forceinline__ size_t eps_tile_point0(jur_chunk_t const &c, int tile) {
+  return c.eps_off ? (size_t)c.eps_off[tile] : (size_t)tile * NLOS;
+}
 struct LosWorkspace {
   double *tile;                 // first double of this wavefront's tile, + lane
   int nfield;
@@ -1223,6 +1228,32 @@ __device__ __forceinline__ void ray_epilogue(double const *__restrict__ sr, doub
   if (write_bbt) rad = JUR_C2 * nu / log1p((JUR_C1 * nu * nu * nu) / rad);
 }
 
+// ---------------------------------------------------------------------------------------
+// Workgroup -> (ray block, item) for the kernels whose workgroups of one ray block share its LOS rows: the hardware
+// deals workgroups to the 8 XCDs round robin (b % 8), each XCD has its own L2, so the `nitem` workgroups of a ray block
+// follow each other on ONE XCD: b -> xcd = b % 8, s = b / 8, ray block = (s / nitem) * 8 + xcd, item = s % nitem --
+// eight ray blocks in flight, one per XCD.  The last, incomplete group of k < 8 ray blocks would leave 8 - k XCDs idle for
+// as long as a whole group takes (a launch of 49 ray blocks x 7134 pairs: 12 % of its time): there the XCDs x with
+// x % k == j share ray block j and split its items between them.  Placement only; every (ray block, item) runs once.
+// ---------------------------------------------------------------------------------------
+struct BlockItem { int rb, item; };
+__host__ __device__ inline unsigned xcd_grid(int nrb, int nitem) {
+  int const full = nrb >> 3, k = nrb & 7;
+  return (unsigned)(full * 8 * nitem + (k ? 8 * ((nitem + (8 / k) - 1) / (8 / k)) : 0));
+}
+__device__ __forceinline__ BlockItem xcd_block_item(int b, int nrb, int nitem) {      // rb < 0: nothing to do
+  int const full = nrb >> 3, k = nrb & 7, nfull = full * 8 * nitem;
+  if (b < nfull) {
+    int const xcd = b & 7, s = b >> 3;
+    return {(s / nitem) * 8 + xcd, s - (s / nitem) * nitem};
+  }
+  if (k == 0) return {-1, 0};
+  int const bb = b - nfull, xcd = bb & 7, s = bb >> 3;
+  int const j = xcd % k, cj = (8 - j + k - 1) / k, q = xcd / k;          // XCDs j, j + k, j + 2k .. share ray block j
+  int const item = s * cj + q;
+  return {item < nitem ? full * 8 + j : -1, item};
+}
+
 // Stage the level and curve descriptors (16 B each) of one (gas, channel) pair in LDS, once per workgroup, with
 // the reciprocal widths of the p and T brackets when the tables are strictly increasing (RCPB).  Ends in a barrier.
 template <bool LDS, bool RCPB>
@@ -1265,9 +1296,9 @@ template <bool WARM, bool LDS, bool RCPB>
 __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
   static_assert(WARM || !RCPB, "reciprocal widths need strictly increasing axes");
   int const npair = v.nd * v.ng;
-  int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
-  int const rb = (sq / npair) * 8 + xcd, pr = sq - (sq / npair) * npair;   // ray block, pair: uniform
-  if (rb >= nrb) return;
+  BlockItem const bi = xcd_block_item((int)blockIdx.x, nrb, npair);
+  int const rb = bi.rb, pr = bi.item;                                       // ray block, pair: uniform
+  if (rb < 0) return;
   int const d = pr / v.ng, g = pr - d * v.ng;
   int const r = rb * blockDim.x + threadIdx.x;
   int const pair_idx = g * v.nd + d;
@@ -1285,7 +1316,7 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   double const *const los_p = los_tile + JUR_F_P * 64, *const los_t = los_tile + JUR_F_T * 64,
                *const los_u = los_tile + (size_t)(JUR_F_K + v.nw + g) * 64;
   size_t const Re = (size_t)npair * 64;                              // ... and from one point's transmittances to the next
-  double *const out = c.eps + (size_t)tile * NLOS * Re + (size_t)pr * 64;
+  double *const out = c.eps + eps_tile_point0(c, tile) * Re + (size_t)pr * 64;
   int const np = c.np[r];
   double tau_path = 1.0;
   unsigned br = 0, ia = 0, ib = 0;
@@ -1340,9 +1371,9 @@ template <int WAVES>
 __global__ __launch_bounds__(1024, WAVES) void jur_ega_group_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
   int const nitems = v.ega_nitems;
   int const BLOCK = (int)blockDim.x;
-  int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
-  int const rb = (sq / nitems) * 8 + xcd, it = sq - (sq / nitems) * nitems;   // ray block, item: uniform
-  if (rb >= nrb) return;
+  BlockItem const bi = xcd_block_item((int)blockIdx.x, nrb, nitems);
+  int const rb = bi.rb, it = bi.item;                                       // ray block, item: uniform
+  if (rb < 0) return;
   jur_item_t const *const item = v.ega_items + it;
   int const g = item->g, nch = item->nch;
   bool const all_curves = item->flags & 1;         // every curve of the item's tables has >= 2 entries (uniform)
@@ -1385,7 +1416,7 @@ __global__ __launch_bounds__(1024, WAVES) void jur_ega_group_kernel(jur_view_t v
   double const *const los_p = los_tile + JUR_F_P * 64, *const los_t = los_tile + JUR_F_T * 64,
                *const los_u = los_tile + (size_t)(JUR_F_K + v.nw + g) * 64;
   size_t const Re = (size_t)v.nd * v.ng * 64;
-  double *const out_tile = c.eps + (size_t)tile * NLOS * Re;
+  double *const out_tile = c.eps + eps_tile_point0(c, tile) * Re;
   int const np = c.np[r];
   double *const mytau = sTau + threadIdx.x;
   unsigned *const mypos = sPos + threadIdx.x;
@@ -1526,9 +1557,9 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
   int const nd = v.nd, ng = v.ng;
   // same XCD-aware order as jur_ega_kernel: the nd workgroups of one ray block follow each other
   // on one XCD and share the block's LOS rows in that L2
-  int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
-  int const rb = (sq / nd) * 8 + xcd, d = sq - (sq / nd) * nd;   // ray block, channel: uniform
-  if (rb >= nrb) return;
+  BlockItem const bi = xcd_block_item((int)blockIdx.x, nrb, nd);
+  int const rb = bi.rb, d = bi.item;                             // ray block, channel: uniform
+  if (rb < 0) return;
   int const r = rb * blockDim.x + threadIdx.x;
   // the channel's source-function table (1201 doubles) is staged in LDS: its two reads per segment are
   // gathers by temperature, everything else this kernel loads is a coalesced stream
@@ -1547,7 +1578,7 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
   unsigned const lane = (unsigned)(r & 63);
   size_t const R = (size_t)nfield * 64, Re = (size_t)nd * ng * 64;   // doubles from one LOS point to the next
   double const *const los = c.los + (size_t)tile * los_tile_doubles(nfield);
-  double const *const epsb = c.eps + (size_t)tile * NLOS * Re + (size_t)d * ng * 64;
+  double const *const epsb = c.eps + eps_tile_point0(c, tile) * Re + (size_t)d * ng * 64;
   jur_chan_t const ch = v.chan[d];
   int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
   bool const do_co2 = (v.fourbit & 8) && ch.co2_on, do_h2o = (v.fourbit & 4) && ch.h2o_on,
@@ -1592,9 +1623,9 @@ __global__ __launch_bounds__(256, 6) void jur_combine_kernel(jur_view_t v, jur_c
 __global__ __launch_bounds__(512, JUR_COMBINE_WAVES) void jur_combine_group_kernel(jur_view_t v, jur_chunk_t c, int nsb, int CG, int SYNC) {   // SYNC: mask, see the loop
   int const nd = v.nd, ng = v.ng;
   int const ncg = (nd + CG - 1) / CG, SUB = (int)(blockDim.x >> 6) / CG;
-  int const b = blockIdx.x, xcd = b & 7, sq = b >> 3;
-  int const sb = (sq / ncg) * 8 + xcd, cg = sq - (sq / ncg) * ncg;   // ray super-block, channel group: uniform
-  if (sb >= nsb) return;
+  BlockItem const bi = xcd_block_item((int)blockIdx.x, nsb, ncg);
+  int const sb = bi.rb, cg = bi.item;                                // ray super-block, channel group: uniform
+  if (sb < 0) return;
   int const w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);   // uniform: channel constants stay in SGPRs
   int const cw = w % CG, sub = w / CG;
   int const d = cg * CG + cw;
@@ -1623,7 +1654,7 @@ __global__ __launch_bounds__(512, JUR_COMBINE_WAVES) void jur_combine_group_kern
   size_t const R = (size_t)nfield * 64, Re = (size_t)nd * ng * 64;   // doubles from one LOS point to the next
   double const *const los = c.los + (size_t)tile * los_tile_doubles(nfield);
   int const dd = live_wave ? d : 0;
-  double const *const epsb = c.eps + (size_t)tile * NLOS * Re + (size_t)dd * ng * 64;
+  double const *const epsb = c.eps + eps_tile_point0(c, tile) * Re + (size_t)dd * ng * 64;
   jur_chan_t const ch = v.chan[dd];
   int const f_k = JUR_F_K + ch.window, f_u = JUR_F_K + v.nw;
   bool const do_co2 = (v.fourbit & 8) && ch.co2_on, do_h2o = (v.fourbit & 4) && ch.h2o_on,
@@ -2039,6 +2070,14 @@ __global__ __launch_bounds__(256) void jur_slopes_kernel(long long n, jur_ue_t c
   }
 }
 
+// longest path of every tile of 64 ray slots (what the tile needs of the transmittance workspace), one wavefront per tile
+__global__ __launch_bounds__(256) void jur_tilemax_kernel(int n, int const *__restrict__ np, int *__restrict__ tile_np) {
+  int const r = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = r < n ? np[r] : 0;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && (r >> 6) < (n + 63) / 64) tile_np[r >> 6] = m;
+}
+
 __global__ __launch_bounds__(256) void jur_raykey_kernel(long nr, long ld, double const *__restrict__ geom,
                                                          double const *__restrict__ atm_time, int atm_np, int by_profile,
                                                          unsigned long long *__restrict__ key, int *__restrict__ id) {
@@ -2302,7 +2341,7 @@ static int launch_ega_group(jur_view_t const *v, jur_chunk_t const *c, hipStream
   int const e = raise_lds_limit(mu, raised, funcs, 3, lds > 64 * 1024);
   if (e) return e;
   int const nrb = (c->n + block - 1) / block;
-  unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * v->ega_nitems);
+  unsigned const grid = xcd_grid(nrb, v->ega_nitems);
   if (waves == 6) hipLaunchKernelGGL((jur_ega_group_kernel<6>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
   else if (waves == 7) hipLaunchKernelGGL((jur_ega_group_kernel<7>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
   else hipLaunchKernelGGL((jur_ega_group_kernel<8>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
@@ -2317,7 +2356,7 @@ extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *
   }
   int const block = 256;
   int const nrb = (c->n + block - 1) / block, npair = v->nd * v->ng;
-  unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * npair);
+  unsigned const grid = xcd_grid(nrb, npair);
   hipStream_t s = (hipStream_t)stream;
   // LDS copy of one pair's descriptors per workgroup: 16 B x (levels + curves of the largest pair)
   // (+ 8 B x the same counts for the reciprocal bracket widths of strictly increasing tables)
@@ -2350,7 +2389,7 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
   if (c->n <= 0) return 0;
   int const block = 256;
   int const nrb = (c->n + block - 1) / block;
-  unsigned const grid = (unsigned)(((nrb + 7) / 8) * 8 * v->nd);
+  unsigned const grid = xcd_grid(nrb, v->nd);
   static std::once_flag env_once;                  // first launch: the environment may override the defaults (A/B
   std::call_once(env_once, [] {                    // switch); once, whichever lane's thread comes first
     if (g_combine_group >= 0) return;              // jur_tune_combine has spoken already
@@ -2372,7 +2411,7 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
   if (group > 0 && v->nd > 1 && fits && (long)c->n * v->nd >= g_combine_min_lanes) {
     int const CG = v->nd < group ? v->nd : group, SUB = 8 / CG, W = CG * SUB;
     int const nsb = (c->n + SUB * 64 - 1) / (SUB * 64), ncg = (v->nd + CG - 1) / CG;
-    unsigned const g2 = (unsigned)(((nsb + 7) / 8) * 8 * ncg);
+    unsigned const g2 = xcd_grid(nsb, ncg);
     int mask = -1;                                 // barrier every 2^k segments, k from JUR_COMBINE_SYNC (<= 0: none)
     if (sync > 0) { mask = 1; while (mask * 2 <= sync) mask *= 2; mask -= 1; }
     hipLaunchKernelGGL(jur_combine_group_kernel, dim3(g2), dim3(64 * W), sizeof(double) * (JUR_TBLNS * CG + 2 + 64), (hipStream_t)stream,
@@ -2381,6 +2420,12 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
   }
   hipLaunchKernelGGL(jur_combine_kernel, dim3(grid), dim3(block), sizeof(double) * (JUR_TBLNS + 64), (hipStream_t)stream, *v, *c,
                      nrb);
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_tile_max(int n, int const *d_np, int *d_tile_np, void *stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(jur_tilemax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, d_np, d_tile_np);
   return (int)hipGetLastError();
 }
 

@@ -53,6 +53,12 @@ struct jur_model {
   long use_rays, use_trace_rays;/* R, Rt of the current call (<= the allocated capacities)     */
   int *d_np;
   double *d_tsurf;
+  int compact_ws;               /* 1 (default): calls that need several integration launches lay the transmittance tiles
+                                   out by the path lengths that occur instead of JUR_NLOS points per ray           */
+  int use_compact;              /* ... and the current call does                                                 */
+  int *d_tile_np, *d_eps_off;   /* [ws_trace_rays / 64] longest path per tile; first point slot of the tile in d_eps */
+  int *h_tile;                  /* pinned: [2][ws_trace_rays / 64] host images of the two                        */
+  long n_launch_ega;            /* integration launches of the last batched call (reporting)                     */
   int *d_status;
   long los_bytes;
   /* ray ordering */
@@ -236,6 +242,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
                                    Measured: 7.7 M rays/s at 1 M rays per launch vs 6.8 M at 131072 (tails, launch fill) */
   m->sort_rays = 1;
   m->ws_budget = 128L << 30;    /* of 288 GB HBM; C3 needs 96 KB per ray */
+  m->compact_ws = getenv("JUR_NO_COMPACT_WS") ? 0 : 1;
   m->trace_mult = 1;
   m->pencil_rays = 10000;       /* measured crossover with the batched kernels (4 channels x 5 emitters) */
   m->pencil_rb = 0;
@@ -494,7 +501,11 @@ static void free_workspace(jur_model_t *m) {
   if (m->d_eps) (void)hipFree(m->d_eps);
   if (m->d_np) (void)hipFree(m->d_np);
   if (m->d_tsurf) (void)hipFree(m->d_tsurf);
-  m->d_los = NULL; m->d_eps = NULL; m->d_np = NULL; m->d_tsurf = NULL; m->los_bytes = 0; m->ws_rays = 0; m->ws_trace_rays = 0;
+  if (m->d_tile_np) (void)hipFree(m->d_tile_np);
+  if (m->d_eps_off) (void)hipFree(m->d_eps_off);
+  if (m->h_tile) (void)hipHostFree(m->h_tile);
+  m->d_los = NULL; m->d_eps = NULL; m->d_np = NULL; m->d_tsurf = NULL; m->d_tile_np = NULL; m->d_eps_off = NULL; m->h_tile = NULL;
+  m->los_bytes = 0; m->ws_rays = 0; m->ws_trace_rays = 0;
 }
 
 static int ensure_workspace(jur_model_t *m, long nr) {
@@ -519,9 +530,22 @@ static int ensure_workspace(jur_model_t *m, long nr) {
     while (mult > 1 && (per_ray_los * mult + per_ray_eps) * R > budget) mult--;
     long Rt = R * mult;
     if (nr < Rt) Rt = (nr + R - 1) / R * R;
+    int compact = 0;
+    if (nr > R && m->compact_ws) {
+      /* Several integration launches with JUR_NLOS points set aside per ray.  Rays rarely have that many (nadir
+       * 181 .. 182, limb 122 .. 393 of 400: SURVEY.md section 6): trace as many rays as the budget allows first -- the
+       * LOS rows are the small part -- and give the rest of it to the transmittances, whose tiles jur_formod_device
+       * then lays out by the longest path of each tile.  R stays the capacity in rays of JUR_NLOS points. */
+      long Rt_c = (nr + 63) / 64 * 64;
+      if (per_ray_los * Rt_c > budget / 2) Rt_c = budget / 2 / per_ray_los / 64 * 64;
+      long R_c = (budget - per_ray_los * Rt_c) / per_ray_eps / 64 * 64;
+      if (R_c > m->chunk_rays) R_c = m->chunk_rays;            /* (the tuning knob: rays of JUR_NLOS points per launch) */
+      if (R_c >= 64 && Rt_c >= R_c) { R = R_c; Rt = Rt_c; compact = 1; }
+    }
     if (R <= m->ws_rays && Rt <= m->ws_trace_rays) {   /* the held workspace serves (smaller strides fit inside it) */
       m->use_rays = R;
       m->use_trace_rays = Rt;
+      m->use_compact = compact;
       return JUR_OK;
     }
     if (!asked) {  /* about to allocate: never plan beyond what the device can give right now (another allocator
@@ -538,12 +562,16 @@ static int ensure_workspace(jur_model_t *m, long nr) {
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_eps, (size_t)per_ray_eps * R);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_np, sizeof(int) * Rt);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_tsurf, sizeof(double) * Rt);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_tile_np, sizeof(int) * (Rt / 64 + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_eps_off, sizeof(int) * (Rt / 64 + 1));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_tile, sizeof(int) * 2 * (Rt / 64 + 1), hipHostMallocDefault);
     if (e == hipSuccess) {
       m->los_bytes = per_ray_los * Rt + per_ray_eps * R;
       m->ws_rays = R;
       m->ws_trace_rays = Rt;
       m->use_rays = R;
       m->use_trace_rays = Rt;
+      m->use_compact = compact;
       return JUR_OK;
     }
     (void)hipGetLastError();
@@ -581,6 +609,8 @@ void jur_model_cost_params(jur_model_t const *m, double *rayds, double *raydz, d
   *rayds = m->view.rayds; *raydz = m->view.raydz; *zmin = m->atm_zmin; *zmax = m->atm_zmax;
 }
 int jur_model_chunk_rays(jur_model_t const *m) { return m->chunk_rays; }
+long jur_model_last_launches(jur_model_t const *m) { return m->n_launch_ega; }
+int jur_model_set_compact_workspace(jur_model_t *m, int on) { m->compact_ws = on ? 1 : 0; return JUR_OK; }
 
 int jur_model_set_sort_rays(jur_model_t *m, int on) { m->sort_rays = on ? 1 : 0; return JUR_OK; }
 
@@ -764,6 +794,7 @@ int jur_formod_device_ld(jur_model_t *m, long nr, double const *d_geom, long ldg
     order = m->d_order;
   }
   long const Rt = m->use_trace_rays;
+  m->n_launch_ega = 0;
 #define TIMED(kind, launch, what)                                                              \
   do {                                                                                         \
     int const ti_ = (m->timing && m->ntimed < JUR_MAX_TIMED) ? m->ntimed++ : -1;               \
@@ -799,6 +830,57 @@ int jur_formod_device_ld(jur_model_t *m, long nr, double const *d_geom, long ldg
       if (t0 == 0) HIPCHK(hipStreamWaitEvent(s, m->ev_mask, 0));
       if (t0 + Rt >= nr) HIPCHK(hipEventRecord(m->ev_trace, s));
     }
+    c.eps_off = NULL;
+    int compact = m->use_compact && nt > R;
+    if (compact) {   /* not while the stream is being captured: the layout needs the path lengths on the host */
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
+      if (st != hipStreamCaptureStatusNone) compact = 0;
+    }
+    if (compact) {
+      /* Tiles laid out by the longest path of each (rays are sorted by tangent altitude: a tile's paths are nearly
+       * equal): the longest path per tile comes back to the host -- the one wait of such a call --, consecutive tiles are
+       * packed into launches of about equal size that fit the transmittance workspace, and every tile's first point
+       * slot goes back up. */
+      long const ntile = (nt + 63) / 64, cap = R / 64 * JUR_NLOS;      /* tile-points the workspace holds */
+      int *const h_np = m->h_tile, *const h_off = m->h_tile + (m->ws_trace_rays / 64 + 1);
+      int const ek = jurk_tile_max((int)nt, m->d_np, m->d_tile_np, s);
+      if (ek) { jur_set_error("tile kernel launch failed: %s", hipGetErrorString((hipError_t)ek)); return JUR_EHIP; }
+      HIPCHK(hipMemcpyAsync(h_np, m->d_tile_np, sizeof(int) * ntile, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      long total = 0;
+      for (long t = 0; t < ntile; t++) total += h_np[t];
+      long const nchunk = (total + cap - 1) / cap > 0 ? (total + cap - 1) / cap : 1;
+      long const target = (total + nchunk - 1) / nchunk;               /* equal shares instead of full launches and a tail */
+      /* first point slot of every tile, restarting per launch; a launch of many tiles ends on a multiple of 32 tiles
+       * (8 ray blocks of 256 rays: one per XCD, see xcd_block_item in jur_kernels.hip) */
+      for (long t = 0; t < ntile;) {
+        long acc = 0, e = t;
+        while (e < ntile && (e == t || (acc + h_np[e] <= cap && acc < target))) acc += h_np[e++];
+        if (e < ntile && e - t >= 64) e = t + (e - t) / 32 * 32;
+        acc = 0;
+        for (long q = t; q < e; q++) { h_off[q] = (int)acc; acc += h_np[q]; h_np[q] = (q == t); }   /* (lengths not needed again: launch starts) */
+        t = e;
+      }
+      HIPCHK(hipMemcpyAsync(m->d_eps_off, h_off, sizeof(int) * ntile, hipMemcpyHostToDevice, s));
+      for (long t0c = 0; t0c < ntile;) {
+        long t1c = t0c + 1;
+        while (t1c < ntile && !h_np[t1c]) t1c++;
+        long const s0 = t0c * 64, s1 = (t1c * 64 < nt) ? t1c * 64 : nt;
+        c.n = (int)(s1 - s0);
+        c.first = t0 + s0;
+        c.order = order ? order + t0 + s0 : NULL;
+        c.np = m->d_np + s0;
+        c.tsurf = m->d_tsurf + s0;
+        c.los = m->d_los + (size_t)s0 * JUR_NLOS * m->nfield;
+        c.eps_off = m->d_eps_off + t0c;
+        TIMED(1, jurk_launch_ega(&m->view, &c, s), "ega");
+        TIMED(2, jurk_launch_combine(&m->view, &c, s), "combine");
+        m->n_launch_ega++;
+        t0c = t1c;
+      }
+      continue;
+    }
     /* integrate it in chunks of R rays; slot s0 of the super-chunk is slot 0 of the chunk */
     for (long s0 = 0; s0 < nt; s0 += R) {
       c.n = (int)((nt - s0 < R) ? nt - s0 : R);
@@ -809,6 +891,7 @@ int jur_formod_device_ld(jur_model_t *m, long nr, double const *d_geom, long ldg
       c.los = m->d_los + (size_t)s0 * JUR_NLOS * m->nfield;   /* tiles of 64 slots, [tile][point][field][64]: s0 is a multiple of 64 */
       TIMED(1, jurk_launch_ega(&m->view, &c, s), "ega");
       TIMED(2, jurk_launch_combine(&m->view, &c, s), "combine");
+      m->n_launch_ega++;
     }
   }
 #undef TIMED

@@ -66,6 +66,9 @@ def lib():
         L.jur_model_table_bytes.argtypes = [C.c_void_p]
         L.jur_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.jur_model_chunk_rays.argtypes = [C.c_void_p]
+        L.jur_model_last_launches.restype = C.c_long
+        L.jur_model_last_launches.argtypes = [C.c_void_p]
+        L.jur_model_set_compact_workspace.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_set_chunk_rays.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_set_sort_rays.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_set_trace_multiple.argtypes = [C.c_void_p, C.c_int]
@@ -351,6 +354,13 @@ class Model:
 
     def workspace_bytes(self):
         return lib().jur_model_workspace_bytes(self.h)
+
+    def last_launches(self):
+        """Integration launches of the last batched call."""
+        return lib().jur_model_last_launches(self.h)
+
+    def set_compact_workspace(self, on):
+        _chk(lib().jur_model_set_compact_workspace(self.h, int(on)))
 
     def table_bytes(self):
         return lib().jur_model_table_bytes(self.h)

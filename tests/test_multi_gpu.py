@@ -191,3 +191,42 @@ def test_channel_group_lookup_kernel_equals_one_pair_per_workgroup(hip, nch):
     for k in ("rad", "tau", "tp", "np"):
         assert same_bits(out[k], ref[k]) and same_bits(chunked[k], ref[k]) and same_bits(back[k], ref[k]), (k, nch)
     m.close()
+
+
+def test_workspace_laid_out_by_path_lengths(hip):
+    """Calls that need several integration launches pack the transmittance tiles by the longest path of each tile
+    instead of JUR_NLOS = 400 points per ray: nadir rays (182 points) then take less than half the launches, a limb scan
+    (122 .. 393) fewer -- and every output equals the one-launch result and the JUR_NLOS-strided chunking bit for bit,
+    for sorted and unsorted rays, a mix with rays that never enter the atmosphere, and a budget-driven layout."""
+    g = synth.limb_geometry(6000, seed=3, nprofiles=2)
+    geom = np.vstack([g[:2500], np.array([[0, 780.0, 0, 0, 95.0, 0, 20.0]] * 70), g[2500:], synth.nadir_geometry(3000, seed=2, nprofiles=2)])
+    case = common.limb_case(geom=geom, nu=common.CTM4_NU, nprofiles=2)
+    m = hip.Model(case.ctl, case.lib_tables())
+    m.set_atm(case.atm)
+    m.set_pencil(0)
+    ref = m.formod_host(case.geom)
+    assert m.last_launches() == 1
+    res = {}
+    for compact in (1, 0):
+        m.set_compact_workspace(compact)
+        for sort in (1, 0):
+            m.set_sort_rays(sort)
+            m.set_chunk_rays(1024)
+            out = m.formod_host(case.geom)
+            res[(compact, sort)] = m.last_launches()
+            for k in ("rad", "tau", "tp", "np"):
+                assert same_bits(out[k], ref[k]), (k, compact, sort)
+    total_points, nr = int(ref["np"].sum()), len(geom)
+    print("launches", res, "LOS points", total_points, "rays", nr)
+    assert res[(0, 1)] == -(-nr // 1024)                                   # JUR_NLOS points per ray: rays / 1024 launches
+    assert res[(1, 1)] <= -(-total_points // (1024 // 64 * 400 * 64 - 64 * 400)) + 1 < res[(0, 1)]   # packed by the points that occur
+    # the same through the workspace budget (what a many-channel set runs into): 96 KB per ray at 400 points
+    m.set_compact_workspace(1)
+    m.set_sort_rays(1)
+    m.set_chunk_rays(1 << 21)
+    m.set_workspace_budget(200 << 20)
+    out = m.formod_host(case.geom)
+    assert m.last_launches() > 1
+    for k in ("rad", "tau", "tp", "np"):
+        assert same_bits(out[k], ref[k]), k
+    m.close()
