@@ -226,6 +226,11 @@ int  jur_model_set_workspace_budget(jur_model_t *m, long bytes);
  * rays_per_group: rays per workgroup, 0 = chosen from the call size.  Configurations with more (channel, gas)
  * chains per ray than the LDS rings hold use the batched kernels whatever the size.  Same results bit for bit. */
 int  jur_model_set_pencil(jur_model_t *m, long max_rays, int rays_per_group);
+/* Process-wide: lanes per ray of the batched ray tracer (1 or 4; 0 = chosen per launch: a quad of lanes per ray for
+ * launches of up to 65 536 rays with at least three emitters, one lane otherwise).  With four lanes the refraction
+ * probes of a step (jr_common.h:665-681) and the emitters' columns are taken side by side; same results bit for bit
+ * (tests/test_multi_gpu.py). */
+void jur_tune_trace(int lanes_per_ray);
 /* Process-wide tuning of the radiance-update kernel of the batched path: up to `channels_per_group` (0 .. 6, default
  * 4; 0 = one channel per workgroup always) channels of a ray block share a workgroup, with a barrier every
  * `sync_segments` segments (default 8; <= 0 none), for launches of at least `min_lanes` rays x channels (default

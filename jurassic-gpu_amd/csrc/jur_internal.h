@@ -125,6 +125,7 @@ int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_tile_max(int n, int const *d_np, int *d_tile_np, void *stream);   /* longest path per tile of 64 slots */
 void jurk_tune_combine(int group, int sync, long min_lanes);
+void jurk_tune_trace(int lanes);
 /* Curtis-Godson columns of the traced chunk: outputs [ray][gas][JUR_NLOS], indexed by ray id */
 int jurk_launch_cg(jur_view_t const *v, jur_chunk_t const *c, double *cgp, double *cgt, double *cgu, void *stream);
 /* bracket slopes of all n table entries (the last entry of a curve gets a value nobody reads) */

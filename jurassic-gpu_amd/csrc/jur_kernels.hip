@@ -328,7 +328,10 @@ __device__ __forceinline__ double quad_bcast(double x) {
 // it (including the coordinates the loop has displaced and restored before it), so the results are the same doubles.
 struct TraceResult { int np; double tsurf, tpz, tplon, tplat; };
 
-template <class Los, bool QUAD = false>
+// LANES = 4 is the QUAD described above, 1 a lane per ray.  (A pair of lanes per ray -- two probes each -- was built and
+// measured in round 4: bit-identical and no faster than one lane at the launch sizes it was meant for, 100 000 rays:
+// profiles/r04_size_sweep.json.)
+template <class Los, int LANES = 1>
 __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double const time, double const obsz, double const obslon,
                                                  double const obslat, double const vpz, double const vplon, double const vplat,
                                                  Los &L, double (&tr_sh)[15][64], int *status) {
@@ -454,8 +457,8 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
       {  // remaining quantities on the same bracket (jr_common.h:557-567)
         double const za = v.atm_z[ia], zb = v.atm_z[ia + 1];
         double const kt = JUR_BOLTZMANN * t, rkt = 1. / kt;   // one division for all emitters' columns (div_rcp)
-        // (QUAD: the four lanes of the ray share the emitters' columns between them; nobody in the tracer reads them back)
-        for (int ig = QUAD ? (int)(threadIdx.x & 3) : 0; ig < v.ng; ig += QUAD ? 4 : 1) {
+        // (LANES > 1: the lanes of the ray share the emitters' columns between them; nobody in the tracer reads them back)
+        for (int ig = LANES > 1 ? (int)(threadIdx.x & (LANES - 1)) : 0; ig < v.ng; ig += LANES) {
           double const *q = v.atm_q + (size_t)ig * v.atm_np;
           double qv;
           if (zdir) qv = lip_rcp(za, q[ia], zb, q[ia + 1], z, rdz); else qv = lip(za, q[ia], zb, q[ia + 1], z);
@@ -495,7 +498,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
         n += refractivity(p, t);
         double xh[3], zz, llon, llat, pp, tt;
         for (int i = 0; i < 3; i++) xh[i] = x[i] + 0.5 * ds * ex0[i];
-        if constexpr (QUAD) {
+        if constexpr (LANES == 4) {
           // one probe per lane of the quad.  The sequential loop displaces a coordinate by h, probes, and takes h
           // off again before it goes on: probe i sees (x_k + h) - h in the coordinates k < i
           double const h = 0.02;
@@ -620,6 +623,31 @@ __global__ __launch_bounds__(64, 4) void jur_trace_kernel(jur_view_t v, jur_chun
   LosWorkspace L{c.los + (size_t)(r >> 6) * los_tile_doubles(JUR_F_K + v.nw + v.ng) + (r & 63), JUR_F_K + v.nw + v.ng};
   TraceResult const t = trace_ray(v, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray], c.geom[4][ray],
                                   c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
+  c.np[r] = t.np;
+  c.tsurf[r] = t.tsurf;
+  if (c.np_out) c.np_out[ray] = t.np;
+  c.tp[0][ray] = t.tpz;
+  c.tp[1][ray] = t.tplon;
+  c.tp[2][ray] = t.tplat;
+}
+
+// The same with a quad of lanes per ray, for launches that leave most of the chip's tracer wavefront slots empty with one
+// lane per ray (up to 65 536 rays: a quad per ray still fits the 4096 slots): the step's dependent chain -- what such a
+// launch waits for -- is shorter by the refraction probes and the emitters' columns the other lanes take.  Same doubles;
+// the lanes of a ray write the same values to the same slots.  Measured (profiles/r04_size_sweep.json): five emitters,
+// 10 000 .. 50 000 limb rays: 1.9 .. 2.0 -> 1.2 .. 1.4 ms; ONE emitter (nadir shape): no gain at 20 000, +15 % at
+// 50 000 -- with a single column there is little to share beside the probes, whose profile look-ups each lane then
+// does for itself.  Hence the rule in jurk_launch_trace.
+template <int LANES>
+__global__ __launch_bounds__(64, 4) void jur_trace_lanes_kernel(jur_view_t v, jur_chunk_t c) {
+  __shared__ double tr_sh[15][64];
+  int const r = blockIdx.x * (64 / LANES) + (int)(threadIdx.x / LANES);   // slot in the chunk
+  if (r >= c.n) return;
+  long const ray = c.order ? (long)c.order[r] : c.first + r;
+  LosWorkspace L{c.los + (size_t)(r >> 6) * los_tile_doubles(JUR_F_K + v.nw + v.ng) + (r & 63), JUR_F_K + v.nw + v.ng};
+  TraceResult const t = trace_ray<LosWorkspace, LANES>(v, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray],
+                                                       c.geom[4][ray], c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
+  if (threadIdx.x & (LANES - 1)) return;
   c.np[r] = t.np;
   c.tsurf[r] = t.tsurf;
   if (c.np_out) c.np_out[ray] = t.np;
@@ -1895,7 +1923,7 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
     if (slot < nray) {
       long const ray = c.first + ray0 + slot;
       LosRing L{ring, &ctl, npr, tsurf, nfield, RB, slot, NC, SH, 0ull};
-      TraceResult const t = trace_ray<LosRing, QUAD>(vt, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray],
+      TraceResult const t = trace_ray<LosRing, QUAD ? 4 : 1>(vt, c.geom[0][ray], c.geom[1][ray], c.geom[2][ray], c.geom[3][ray],
                                                      c.geom[4][ray], c.geom[5][ray], c.geom[6][ray], L, tr_sh, c.status);
       if ((lane & ((1 << SH) - 1)) == 0) {
         if (c.np_out) c.np_out[ray] = t.np;
@@ -2300,11 +2328,20 @@ extern "C" int jurk_prepare_atm(jur_view_t const *v, double *d_pslope, void *str
   return (int)hipGetLastError();
 }
 
+static int g_trace_lanes = 0;          // 0: by launch size
+extern "C" void jurk_tune_trace(int lanes) { g_trace_lanes = (lanes == 1 || lanes == 4) ? lanes : 0; }
+
 extern "C" int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void *stream) {
   if (c->n <= 0) return 0;
   int const block = 64;
-  int const grid = (c->n + block - 1) / block;
-  hipLaunchKernelGGL(jur_trace_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *v, *c);
+  // a quad of lanes per ray where the launch stays within the chip's 4096 tracer wavefront slots with it AND the rays
+  // have several emitters' columns to share (see jur_trace_lanes_kernel)
+  static int const env_lanes = getenv("JUR_TRACE_LANES") ? atoi(getenv("JUR_TRACE_LANES")) : 0;     // A/B switch, read once
+  int const forced = g_trace_lanes ? g_trace_lanes : env_lanes;
+  int const lanes = forced == 1 || forced == 4 ? forced : ((c->n <= 65536 && v->ng >= 3) ? 4 : 1);
+  int const grid = (int)(((long)c->n * lanes + block - 1) / block);
+  if (lanes == 4) hipLaunchKernelGGL(jur_trace_lanes_kernel<4>, dim3(grid), dim3(block), 0, (hipStream_t)stream, *v, *c);
+  else hipLaunchKernelGGL(jur_trace_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *v, *c);
   return (int)hipGetLastError();
 }
 

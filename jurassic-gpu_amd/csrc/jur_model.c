@@ -639,6 +639,8 @@ int jur_model_set_pencil(jur_model_t *m, long max_rays, int rays_per_group) {
   return JUR_OK;
 }
 
+void jur_tune_trace(int lanes_per_ray) { jurk_tune_trace(lanes_per_ray); }
+
 void jur_tune_combine(int channels_per_group, int sync_segments, long min_lanes) {
   jurk_tune_combine(channels_per_group, sync_segments, min_lanes);
 }

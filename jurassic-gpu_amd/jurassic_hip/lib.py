@@ -87,6 +87,8 @@ def lib():
         L.jur_formod_device_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.POINTER(C.c_long)] + [C.c_void_p] * 7
         L.jur_tune_combine.argtypes = [C.c_int, C.c_int, C.c_long]
         L.jur_tune_combine.restype = None
+        L.jur_tune_trace.argtypes = [C.c_int]
+        L.jur_tune_trace.restype = None
         L.jur_state_size.restype = C.c_size_t
         L.jur_state_size.argtypes = [C.c_void_p, C.c_void_p]
         L.jur_measurement_size.restype = C.c_size_t
@@ -453,6 +455,11 @@ def fov_apply(time, vpz, rad, tau, dz, w):
 
 def formod_pencil(ctl, atm, obs, ir):
     lib().formod_pencil(C.byref(ctl), C.byref(atm), C.byref(obs), ir)
+
+
+def tune_trace(lanes_per_ray=0):
+    """Process-wide: lanes per ray of the batched ray tracer (0: chosen per launch)."""
+    lib().jur_tune_trace(lanes_per_ray)
 
 
 def tune_combine(channels_per_group=4, sync_segments=8, min_lanes=1_000_000):

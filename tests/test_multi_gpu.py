@@ -230,3 +230,34 @@ def test_workspace_laid_out_by_path_lengths(hip):
     for k in ("rad", "tau", "tp", "np"):
         assert same_bits(out[k], ref[k]), k
     m.close()
+
+
+def test_tracer_with_four_lanes_per_ray(hip):
+    """The batched ray tracer with a quad of lanes per ray (what launches of up to 65 536 rays with several emitters take):
+    the refraction probes of a step side by side, each as the sequential loop sees it -- every output bit for bit equal
+    to one lane per ray: limb and nadir rays, refraction off, rays outside / observer inside, NLOS overflow reported."""
+    g = synth.limb_geometry(2200, seed=9, nprofiles=3)
+    extra = np.array([[0, 780.0, 0, 0, 95.0, 0, 20.0], [1, 30.0, 0, 0, 5.0, 0, 3.0], [2, 780.0, 0, 0, -0.005, 0, 27.0]])
+    geom = np.vstack([g[:900], extra, g[900:], synth.nadir_geometry(333, seed=2, nprofiles=3)])
+    try:
+        for kw in (dict(), dict(refrac=0), dict(raydz=0.2)):
+            case = common.limb_case(geom=geom, nprofiles=3, **kw)
+            m = hip.Model(case.ctl, case.lib_tables())
+            m.set_atm(case.atm)
+            m.set_pencil(0)
+            res = {}
+            for lanes in (1, 4):
+                hip.tune_trace(lanes)
+                try:
+                    res[lanes] = m.formod_host(case.geom)
+                except hip.JurassicError as e:            # raydz = 0.2: more than NLOS points, whatever the lanes
+                    res[lanes] = str(e)
+            if isinstance(res[1], str):
+                assert "LOS" in res[1] and res[4] == res[1]
+            else:
+                for lanes in (4,):
+                    for k in ("rad", "tau", "tp", "np"):
+                        assert same_bits(res[lanes][k], res[1][k]), (k, lanes, kw)
+            m.close()
+    finally:
+        hip.tune_trace(0)
