@@ -3,7 +3,7 @@
 #   tools/ab_env.sh "JUR_X=0" "JUR_X=1" ...
 for e in "$@"; do
   echo "$e"
-  env $e python3 bench.py --steps 5 --no-cpu-baseline --no-host-inclusive --no-package-api 2>/dev/null | python3 -c "
+  env $e python3 bench.py --steps 5 --no-cpu-baseline --no-host-inclusive --no-package-api --no-extra 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 k = d['roofline']['kernels']

@@ -15,7 +15,7 @@ for set in "${SETS[@]}"; do
   for pass in "${PASSES[@]}"; do
     pn=${pass%% *}
     ( export $envs; timeout -k 10 300 rocprofv3 --pmc ${pass#* } --output-format csv -d "$OUT/$name/$pn" -- \
-      python3 "$ROOT/bench.py" --no-cpu-baseline --no-host-inclusive --no-package-api --workload ${WORKLOAD:-limb_1e6} --rays ${RAYS:-1000000} --steps 1 --warmup 0 > "$OUT/${name}_$pn.log" 2>&1 ) || { echo "pass $pn of $name failed"; tail -3 "$OUT/${name}_$pn.log"; exit 1; }
+      python3 "$ROOT/bench.py" --no-cpu-baseline --no-host-inclusive --no-package-api --no-extra --workload ${WORKLOAD:-limb_1e6} --rays ${RAYS:-1000000} --steps 1 --warmup 0 > "$OUT/${name}_$pn.log" 2>&1 ) || { echo "pass $pn of $name failed"; tail -3 "$OUT/${name}_$pn.log"; exit 1; }
   done
   python3 - "$OUT/$name" "${KERNEL:-jur_ega}" "$name" <<'PY'
 import collections, csv, glob, os, sys

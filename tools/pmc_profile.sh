@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 BENCH_ARGS="${@:---rays 1000000 --steps 1 --warmup 0}"
 pass() {
   name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-host-inclusive --no-package-api $BENCH_ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; }
+  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-host-inclusive --no-package-api --no-extra $BENCH_ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; }
   echo "pass $name done"
 }
 pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES
