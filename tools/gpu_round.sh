@@ -21,6 +21,7 @@ for w in $WHAT; do
   case $w in
     tests) step gpu_tests 1100 python3 -m pytest tests -q -m gpu -p no:cacheprovider ;;
     bench) TAIL=1 step bench 600 python3 bench.py --steps 5 ;;
+    airs) TAIL=1 step bench_airs 900 python3 bench.py --workload airs_2378_sharded --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --no-package-api ;;
     nadir) TAIL=1 step bench_nadir 300 python3 bench.py --workload nadir_1e5 --steps 20 --no-cpu-baseline ;;
     small) TAIL=1 step small 300 python3 tools/bench_small.py ;;
     lanes) TAIL=5 step lanes 300 bash tools/run_lanes_bench.sh ;;
@@ -73,7 +74,7 @@ PY
            TAIL=1 JUR_PENCIL_RAYS=0 JUR_LANES=16 step lanes_hwq 300 $D/lanes_bench 16 16      # batched kernels, 16 lanes
            cd $GRAFT_REPO_ROOT ;;
     stats) cd /tmp; export TMPDIR=/tmp
-           step kernel_stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --no-cpu-baseline --no-host-inclusive --no-package-api
+           step kernel_stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --no-cpu-baseline --no-host-inclusive --no-package-api --no-extra
            cd $GRAFT_REPO_ROOT ;;
   esac
 done
