@@ -38,6 +38,17 @@ void formod_fov(ctl_t const *ctl, obs_t *obs);
  * track) or 3 (distance-weighted mean of a point cloud, ctl->cx / ctl->cz); GPU, device ctl->MPIlocalrank */
 void intpol_atm(ctl_t *ctl, atm_t *atm_dest, atm_t *atm_src);
 
+/* kernel() (reference jurassic.h:664, jurassic.c:812-857): forward-difference Jacobian of the finite radiances with
+ * respect to the state elements inside the ctl->ret*_zmin/zmax windows, as ONE batched forward-model call on the GPU
+ * (the difference quotients are formed on the device too); obs returns the unperturbed forward model.  The reference's
+ * last argument is a gsl_matrix *: this library does not depend on GSL, jur_gsl_matrix_t restates that struct's layout
+ * (gsl/gsl_matrix_double.h, unchanged since GSL 1.0: size1, size2, tda, data, block, owner) -- a caller that has GSL
+ * passes its gsl_matrix * (same object), one that has not fills the first four fields.  size1 must be the number of
+ * finite radiances of obs, size2 the state size (what obs2y / atm2x return upstream; jur_measurement_size /
+ * jur_state_size here). */
+typedef struct { size_t size1, size2, tda; double *data; void *block; int owner; } jur_gsl_matrix_t;
+void kernel(ctl_t const *ctl, atm_t *atm, obs_t *obs, jur_gsl_matrix_t *k);
+
 /* ---- (2) additive --------------------------------------------------------- */
 enum {
   JUR_OK = 0,
@@ -156,7 +167,8 @@ int  jur_formod_device_multi(jur_model_t *const models[], int nmodel, long nr, l
  * vectors as atm2x/obs2y, :1491-1541): forward-difference Jacobian dy/dx of the
  * finite radiances with respect to the atmosphere values inside the
  * ctl->ret{p,t,q,k}_zmin/zmax windows, evaluated as one batched forward-model
- * call (n+1 stacked atmospheres).  k is row-major [jur_measurement_size][jur_state_size];
+ * call (n+1 stacked atmospheres) whose difference quotients are formed on the device.  k is row-major
+ * [jur_measurement_size][jur_state_size];
  * obs returns the unperturbed result.  The reference's signature takes a gsl_matrix;
  * bind with k = matrix->data when matrix->tda == matrix->size2. */
 size_t jur_state_size(jur_model_t const *m, atm_t const *atm);

@@ -123,7 +123,9 @@ int jurk_prepare_atm(jur_view_t const *v, double *d_pslope, void *stream);   /* 
 int jurk_launch_trace(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *stream);
 int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, void *stream);
-int jurk_tile_max(int n, int const *d_np, int *d_tile_np, void *stream);   /* longest path per tile of 64 slots */
+int jurk_tile_max(int n, int const *d_np, int *d_tile_np, void *stream);
+/* dense difference quotients kq[nq][n] from rad[(n + 1) * nq] (nq = rays x channels of the unperturbed block) and steps h[n] */
+int jurk_launch_kquot(long nq, long n, double const *d_rad, double const *d_h, double *d_kq, void *stream);   /* longest path per tile of 64 slots */
 void jurk_tune_combine(int group, int sync, long min_lanes);
 void jurk_tune_trace(int lanes);
 /* Curtis-Godson columns of the traced chunk: outputs [ray][gas][JUR_NLOS], indexed by ray id */

@@ -2098,6 +2098,17 @@ __global__ __launch_bounds__(256) void jur_slopes_kernel(long long n, jur_ue_t c
   }
 }
 
+// Difference quotients of the batched Jacobian (kernel(), jurassic.c:853-855): the radiances of the n perturbed copies
+// of the nr rays stand behind the unperturbed ones, rad[(e + 1) * nr + i][id]; dense rows q = i * nd + id, columns e:
+// kq[q][e] = (y1 - y0) / h[e].  One lane per element, columns fastest.
+__global__ __launch_bounds__(256) void jur_kquot_kernel(long nq, long n, long nrnd, double const *__restrict__ rad,
+                                                        double const *__restrict__ h, double *__restrict__ kq) {
+  long const t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nq * n) return;
+  long const q = t / n, e = t - q * n;
+  kq[t] = (rad[(e + 1) * nrnd + q] - rad[q]) / h[e];
+}
+
 // longest path of every tile of 64 ray slots (what the tile needs of the transmittance workspace), one wavefront per tile
 __global__ __launch_bounds__(256) void jur_tilemax_kernel(int n, int const *__restrict__ np, int *__restrict__ tile_np) {
   int const r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2457,6 +2468,12 @@ extern "C" int jurk_launch_combine(jur_view_t const *v, jur_chunk_t const *c, vo
   }
   hipLaunchKernelGGL(jur_combine_kernel, dim3(grid), dim3(block), sizeof(double) * (JUR_TBLNS + 64), (hipStream_t)stream, *v, *c,
                      nrb);
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_launch_kquot(long nq, long n, double const *d_rad, double const *d_h, double *d_kq, void *stream) {
+  if (nq <= 0 || n <= 0) return 0;
+  hipLaunchKernelGGL(jur_kquot_kernel, dim3((unsigned)((nq * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nq, n, nq, d_rad, d_h, d_kq);
   return (int)hipGetLastError();
 }
 

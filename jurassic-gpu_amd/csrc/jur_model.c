@@ -88,6 +88,8 @@ struct jur_model {
   /* field-of-view convolution of device arrays: grow-only scratch and its own status word */
   double *d_fov;
   long fov_cap;
+  double *d_kq, *h_kq;          /* jur_kernel: perturbation steps and dense difference quotients (device, pinned host) */
+  long kq_cap;
   /* small calls: the fused kernel (jur_pencil_kernel) instead of sort + three batched kernels */
   long pencil_rays;             /* calls of up to this many rays take it (0: never)             */
   int pencil_rb;                /* rays per workgroup (0: chosen from the call size)            */
@@ -335,11 +337,12 @@ void jur_model_destroy(jur_model_t *m) {
   (void)hipSetDevice(m->device);
   if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_pair_e0 = m->d_lvl = m->d_crv = m->d_ue = m->d_sl = m->d_items = NULL;
   void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_pair_e0, m->d_lvl, m->d_crv, m->d_ue, m->d_sl, m->d_items, m->d_atm, m->d_order, m->d_sort_tmp,
-                  m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np, m->d_fov};
+                  m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np, m->d_fov, m->d_kq};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
     if (ptrs[i]) (void)hipFree(ptrs[i]);
   if (m->h_io) (void)hipHostFree(m->h_io);
   if (m->h_pkg) (void)hipHostFree(m->h_pkg);
+  if (m->h_kq) (void)hipHostFree(m->h_kq);
   if (m->h_status) (void)hipHostFree(m->h_status);
   free(m->h_atm);
   if (!m->shared_tables) { free(m->grid_cls); free(m->grid_all); free(m->h_pair_e0); }
@@ -1283,7 +1286,13 @@ size_t jur_measurement_size(jur_model_t const *m, obs_t const *obs) {
 /* Forward-difference Jacobian (kernel(), jurassic.c:812-857) as ONE batched forward-model call:
  * the n perturbed atmospheres are stacked behind the unperturbed one as further profile slices
  * (time stamps shifted by j * span) and every ray is replicated once per slice. */
+static int kernel_ld(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t mrows, size_t ncols, size_t ldk);
+
 int jur_kernel(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t mrows, size_t ncols) {
+  return kernel_ld(m, atm, obs, k, mrows, ncols, ncols);
+}
+
+static int kernel_ld(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t mrows, size_t ncols, size_t ldk) {
   if (!m || !atm || !obs || !k) { jur_set_error("jur_kernel: null argument"); return JUR_EINVAL; }
   ctl_t const *ctl = m->ctl;
   int const np0 = atm->np, nr = obs->nr, nd = ctl->nd, ng = m->view.ng, nw = m->view.nw;
@@ -1298,9 +1307,12 @@ int jur_kernel(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t m
   size_t const ncopy = n + 1, nrow = 6 + (size_t)ng + nw;
   size_t const NT = ncopy * (size_t)np0, NRT = ncopy * (size_t)nr;
   double *h = (double *)malloc(sizeof(double) * nrow * NT);
-  double *g = (double *)malloc(sizeof(double) * (10 + 2 * (size_t)nd) * NRT);
+  double *g = NULL;                                /* the model's pinned image of the call's arrays (ensure_io) */
   int rc = JUR_OK;
-  if (!x0 || !hstep || !iqa || !ipa || !h || !g) { rc = JUR_ENOMEM; goto done; }
+  if (!x0 || !hstep || !iqa || !ipa || !h) { rc = JUR_ENOMEM; goto done; }
+  if (hipSetDevice(m->device) != hipSuccess) { jur_set_error("jur_kernel: cannot select the device"); rc = JUR_EHIP; goto done; }
+  if ((rc = ensure_io(m, (long)NRT, 1))) goto done;
+  g = m->h_io;
   {
     double tmin = atm->time[0], tmax = atm->time[0];
     for (int i = 0; i < np0; i++) { tmin = fmin(tmin, atm->time[i]); tmax = fmax(tmax, atm->time[i]); }
@@ -1329,9 +1341,9 @@ int jur_kernel(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t m
     if (rc) goto done;
     double *geom[7], *tp[3], *rad, *tau;
     for (int q = 0; q < 7; q++) geom[q] = g + (size_t)q * NRT;
-    for (int q = 0; q < 3; q++) tp[q] = g + (size_t)(7 + q) * NRT;
-    rad = g + 10 * NRT;
+    rad = g + 7 * NRT;                             /* the image's layout: geom[7][N] | rad[N][nd] | tau[N][nd] | tp[3][N] */
     tau = rad + (size_t)nd * NRT;
+    for (int q = 0; q < 3; q++) tp[q] = tau + (size_t)nd * NRT + (size_t)q * NRT;
     double const *src[7] = {obs->time, obs->obsz, obs->obslon, obs->obslat, obs->vpz, obs->vplon, obs->vplat};
     for (size_t j = 0; j < ncopy; j++)
       for (int i = 0; i < nr; i++) {
@@ -1340,28 +1352,54 @@ int jur_kernel(jur_model_t *m, atm_t const *atm, obs_t *obs, double *k, size_t m
         for (int q = 1; q < 7; q++) geom[q][r] = src[q][i];
         for (int id = 0; id < nd; id++) rad[r * nd + id] = obs->rad[i][id];   /* carries the NaN mask */
       }
-    double const *cgeom[7] = {geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6]};
-    rc = jur_formod_host(m, (long)NRT, cgeom, rad, tau, tp, NULL);
-    if (rc) goto done;
+    /* One batched call on device arrays; the difference quotients are formed there too (jur_kquot_kernel) and only
+     * the unperturbed block and the quotients come back. */
+    size_t const nq = (size_t)nr * nd, nrd = NRT * (size_t)nd;
+    if ((long)(nq * n + n) > m->kq_cap) {
+      if (m->d_kq) (void)hipFree(m->d_kq);
+      if (m->h_kq) (void)hipHostFree(m->h_kq);
+      m->d_kq = NULL; m->h_kq = NULL; m->kq_cap = 0;
+      if (hipMalloc((void **)&m->d_kq, sizeof(double) * (nq * n + n)) != hipSuccess ||
+          hipHostMalloc((void **)&m->h_kq, sizeof(double) * (nq * n + n), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError(); jur_set_error("jur_kernel: no memory for the quotients"); rc = JUR_ENOMEM; goto done;
+      }
+      m->kq_cap = (long)(nq * n + n);
+    }
+    hipStream_t const s = m->stream;
+    double *const d_geom = m->d_io, *const d_rad = d_geom + 7 * NRT, *const d_tau = d_rad + nrd, *const d_tp = d_tau + nrd;
+    double *const d_h = m->d_kq, *const d_kq = m->d_kq + n;
+    int status = 0;
+    memcpy(m->h_kq, hstep, sizeof(double) * n);
+    hipError_t e = hipMemcpyAsync(d_geom, g, sizeof(double) * (7 * NRT + nrd), hipMemcpyHostToDevice, s);   /* geometry | input radiances */
+    if (e == hipSuccess) e = hipMemcpyAsync(d_h, m->h_kq, sizeof(double) * n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(m->d_status, 0, sizeof(int), s);
+    if (e != hipSuccess) { jur_set_error("jur_kernel: %s", hipGetErrorString(e)); rc = JUR_EHIP; goto done; }
+    if ((rc = jur_formod_device(m, (long)NRT, d_geom, d_rad, d_tau, d_tp, NULL, m->d_status, s))) goto done;
+    if (jurk_launch_kquot((long)nq, (long)n, d_rad, d_h, d_kq, s)) { jur_set_error("jur_kernel: quotient kernel launch failed"); rc = JUR_EHIP; goto done; }
+    double *const kq = m->h_kq + n;
+    e = hipMemcpyAsync(kq, d_kq, sizeof(double) * nq * n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(rad, d_rad, sizeof(double) * nq, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(tau, d_tau, sizeof(double) * nq, hipMemcpyDeviceToHost, s);
+    for (int q = 0; q < 3 && e == hipSuccess; q++) e = hipMemcpyAsync(tp[q], d_tp + (size_t)q * NRT, sizeof(double) * nr, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&status, m->d_status, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { jur_set_error("jur_kernel: %s", hipGetErrorString(e)); rc = JUR_EHIP; goto done; }
+    if (status) { jur_set_error("Too many LOS points!"); rc = JUR_ENLOS; goto done; }
     for (int i = 0; i < nr; i++) {   /* unperturbed result back to the caller, as kernel() leaves it */
       for (int id = 0; id < nd; id++) { obs->rad[i][id] = rad[(size_t)i * nd + id]; obs->tau[i][id] = tau[(size_t)i * nd + id]; }
       for (int id = nd; id < JUR_ND; id++) { obs->rad[i][id] = 0.0; obs->tau[i][id] = 1.0; }
       obs->tpz[i] = tp[0][i]; obs->tplon[i] = tp[1][i]; obs->tplat[i] = tp[2][i];
     }
     size_t row = 0;
-    for (int i = 0; i < nr; i++)
-      for (int id = 0; id < nd; id++) {
-        double const y0 = rad[(size_t)i * nd + id];
-        if (!isfinite(y0)) continue;               /* obs2y, jurassic.c:1527-1541 */
-        for (size_t e = 0; e < n; e++) {
-          double const y1 = rad[((e + 1) * (size_t)nr + i) * nd + id];
-          k[row * n + e] = (y1 - y0) / hstep[e];
-        }
-        row++;
-      }
+    for (size_t q = 0; q < nq; q++) {              /* rows of the finite measurements (obs2y, jurassic.c:1527-1541) */
+      if (!isfinite(rad[q])) continue;
+      if (row < mrows) memcpy(k + row * ldk, kq + q * n, sizeof(double) * n);
+      row++;
+    }
+    if (row != mrows) { jur_set_error("jur_kernel: %zu finite measurements after the forward model, the matrix has %zu rows", row, mrows); rc = JUR_EINVAL; }
   }
 done:
-  free(x0); free(hstep); free(iqa); free(ipa); free(h); free(g);
+  free(x0); free(hstep); free(iqa); free(ipa); free(h);
   if (rc == JUR_OK) rc = jur_model_set_atm(m, atm);   /* leave the model with the caller's atmosphere */
   return rc;
 }
@@ -1404,7 +1442,7 @@ static jur_model_t *clone_lane(jur_model_t const *m) {
   c->d_io = NULL; c->d_io_np = NULL; c->io_cap = 0;
   c->h_io = NULL; c->h_io_cap = 0; c->h_pkg = NULL; c->h_atm = NULL; c->h_atm_n = 0; c->h_atm_cap = 0; c->h_status = NULL;
   c->stream = NULL; c->stream2 = NULL; c->ev_mask = NULL; c->ev_trace = NULL;
-  c->host_call = 0; c->have_done = 0; c->ev_done = NULL; c->d_fov = NULL; c->fov_cap = 0;
+  c->host_call = 0; c->have_done = 0; c->ev_done = NULL; c->d_fov = NULL; c->fov_cap = 0; c->d_kq = NULL; c->h_kq = NULL; c->kq_cap = 0;
   c->timing = 0; c->evpool = NULL; c->evkind = NULL; c->ntimed = 0;
   if (hipSetDevice(c->device) != hipSuccess || create_streams(c) != JUR_OK ||
       hipMalloc((void **)&c->d_status, sizeof(int)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
@@ -1539,3 +1577,19 @@ void formod(ctl_t const *ctl, atm_t *atm, obs_t *obs) {
 }
 
 void formod_pencil(ctl_t const *ctl, atm_t *atm, obs_t *obs, int const ir) { formod_range(ctl, atm, obs, ir, 1); }
+
+/* kernel() under its own name (jurassic.h:664, jurassic.c:812-857): the Jacobian into a gsl_matrix of
+ * (finite measurements) x (state elements).  GSL is not a dependency of this library: jur_gsl_matrix_t restates the
+ * layout of gsl_matrix (include/jurassic_hip.h).  obs returns the unperturbed forward model, as upstream. */
+void kernel(ctl_t const *ctl, atm_t *atm, obs_t *obs, jur_gsl_matrix_t *k) {
+  if (!ctl || !atm || !obs || !k || !k->data) DIE("null argument");
+  if (ctl->checkmode) { printf("# %s: no operation in checkmode\n", __func__); return; }
+  if (k->tda < k->size2) DIE("matrix with tda < size2");
+  int const lane = acquire_lane(ctl);
+  jur_model_t *m = g_lane[lane];
+  /* (upstream sizes the matrix from obs2y / atm2x of the caller's obs and atm before the call, retrieval.c; so does the caller here) */
+  int const rc = kernel_ld(m, atm, obs, k->data, k->size1, k->size2, k->tda);
+  if (rc == JUR_ENLOS) DIE("Too many LOS points!");
+  if (rc != JUR_OK) DIE("%s", jur_last_error());
+  release_lane(lane);
+}

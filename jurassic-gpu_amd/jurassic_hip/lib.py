@@ -101,6 +101,8 @@ def lib():
         for name in ("formod", "formod_GPU"):
             getattr(L, name).argtypes = [C.c_void_p] * 3
             getattr(L, name).restype = None
+        L.kernel.argtypes = [C.c_void_p] * 4
+        L.kernel.restype = None
         L.formod_pencil.argtypes = [C.c_void_p] * 3 + [C.c_int]
         L.formod_pencil.restype = None
         _lib = L
@@ -369,6 +371,23 @@ class Model:
 
 
 ARITH_FAST, ARITH_EXACT = 0, 1
+
+
+class GslMatrix(C.Structure):
+    """Layout of GSL's gsl_matrix (jur_gsl_matrix_t): what the reference's kernel() takes."""
+    _fields_ = [("size1", C.c_size_t), ("size2", C.c_size_t), ("tda", C.c_size_t), ("data", dp), ("block", C.c_void_p),
+                ("owner", C.c_int)]
+
+
+def kernel(ctl, atm, obs, m, n, tda=None):
+    """Drop-in kernel() (reference jurassic.c:812): -> (m, n) Jacobian; obs receives the unperturbed forward model.
+    tda > n exercises a matrix whose rows are longer than its width (a sub-matrix view)."""
+    tda = tda or n
+    store = np.full((m, tda), -7.0)
+    mat = GslMatrix(m, n, tda, _p(store), None, 0)
+    lib().kernel(C.byref(ctl), C.byref(atm), C.byref(obs), C.byref(mat))
+    assert np.all(store[:, n:] == -7.0)               # nothing written beyond the matrix's width
+    return store[:, :n].copy()
 
 
 def device_info(device):

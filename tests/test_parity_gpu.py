@@ -744,6 +744,54 @@ def test_jacobian_matches_reference_kernel(hip, oracle, kw, arith):
     model.close()
 
 
+DROPIN_KERNEL = r"""
+import os, sys
+sys.path[:0] = [{root!r}, os.path.join({root!r}, 'jurassic-gpu_amd'), os.path.join({root!r}, 'tests')]
+import numpy as np, common
+from oracle import orc
+from jurassic_hip import abi, lib, textio
+case = common.limb_case(useGPU=1)
+c = case.ctl
+c.rett_zmin, c.rett_zmax = 10.0, 40.0
+c.retq_zmin[2], c.retq_zmax[2] = 15.0, 35.0
+case.write_files({tmp!r}, base='boxcar')
+tb = orc.Tables(c.ng, c.nd); assert tb.read_ascii(c) == 0 and tb.planck_filt(c) == 0
+
+def obs_of(geom):
+    o = abi.obs_t()
+    o.nr = len(geom)
+    for k, name in enumerate(textio.OBS_COLS[:7]):
+        np.ctypeslib.as_array(getattr(o, name))[:o.nr] = geom[:, k]
+    return o
+obs_ref, obs = obs_of(case.geom), obs_of(case.geom)
+for o in (obs_ref, obs):
+    o.rad[3][0] = float('nan')                         # a masked measurement drops its row
+k_ref = orc.kernel(c, case.atm, obs_ref, tb)
+m, n = k_ref.shape
+assert (m, n) == (66 * 2 - 1, 31 + 21)
+k = lib.kernel(c, case.atm, obs, m, n, tda=n + 5)      # the reference's symbol, a gsl_matrix with tda > size2
+scale = np.abs(k_ref).max(axis=0)
+assert np.max(np.abs(k - k_ref) / scale) < 1e-6
+a, b = np.ctypeslib.as_array(obs.rad)[:66, :2], np.ctypeslib.as_array(obs_ref.rad)[:66, :2]
+fin = np.isfinite(b)
+assert np.array_equal(fin, np.isfinite(a)) and np.max(np.abs(a[fin] - b[fin]) / b[fin]) < 1e-9
+again = obs_of(case.geom)
+lib.formod(c, case.atm, again)                         # the lane is left with the caller's atmosphere
+assert np.max(np.abs(np.ctypeslib.as_array(again.rad)[:66, :2][fin] - b[fin]) / b[fin]) < 1e-9
+print('DROPIN_KERNEL_OK')
+"""
+
+
+def test_drop_in_kernel_symbol_takes_a_gsl_matrix(hip, oracle, tmp_path):
+    """kernel(ctl, atm, obs, gsl_matrix *) under its own name (jurassic.c:812-857): tables from the files ctl names,
+    the Jacobian written into a matrix whose row stride exceeds its width, a masked measurement dropped, obs left with
+    the unperturbed forward model -- against the oracle's restatement of the reference loop."""
+    script = tmp_path / "dropin_kernel.py"
+    script.write_text(DROPIN_KERNEL.format(root=common.ROOT, tmp=str(tmp_path)))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DROPIN_KERNEL_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 def test_jacobian_columns_are_as_near_the_derivative_as_the_reference_ones(hip, oracle):
     """Difference quotients divide the rounding noise of y by h.  For optically thin rays the ALGORITHM forms a segment's
     emissivity as 1 - (1 - 1e-9): y is good to ~1e-12 relative only, in the reference as here, and implementations that
