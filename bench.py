@@ -344,7 +344,9 @@ def roofline_block(workload, kms, nrays_step, steps, sum_np, shape, ab):
     else:   # no counters of this code version: the one fraction this run can measure by itself
         block.update(bound="hbm", achieved=dom["hbm_compulsory_frac"] * HBM_PEAK / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                      frac=dom["hbm_compulsory_frac"], traffic=None, pmc_source=None, pmc_missing=why)
-    block["note"] = ("frac is a fraction of the named bound's peak for the dominant kernel.  Durations: THIS run's "
+    block["note"] = ("frac is a fraction of the named bound's peak for the dominant kernel (valu_fp64_issue: one wavefront "
+                     "instruction per 4 cycles and SIMD, the fp64 rate -- 32-bit instructions issue in 2 cycles, so a stream "
+                     "with many of them can read slightly above 1: the many-channel look-up does, 1.03).  Durations: THIS run's "
                      "event-timed launches.  VALU instruction and HBM byte counts per launch: NOT counters of this run -- "
                      "a rocprofv3 --pmc pass of the same device code on the builder's box (profiles/pmc_current.json, "
                      "tools/pmc_profile.sh), scaled by rays per launch and refused when the kernel sources changed since")
