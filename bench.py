@@ -42,8 +42,11 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "jurassic-gpu_amd"), os.path.join(ROOT,
 
 HBM_PEAK = 8.0e12                    # B/s, MI355X_MICROARCH.md
 VALU_PEAK = 256 * 4 * 2.4e9 / 4      # wavefront VALU instructions/s: 1024 SIMDs, one fp64 instruction per 4 cycles
+# what the device code is built from: the kernels, the structures they share with the host, the compile-time dimensions
+# and constants, the build flags.  (include/jurassic_hip.h -- prototypes of the C-ABI only -- was part of this list until
+# round 4; a new entry point there does not change a kernel.)
 KERNEL_SOURCES = ["jurassic-gpu_amd/csrc/jur_kernels.hip", "jurassic-gpu_amd/csrc/jur_internal.h",
-                  "jurassic-gpu_amd/csrc/Makefile", "include/jurassic_hip.h", "include/jurassic_abi.h"]
+                  "jurassic-gpu_amd/csrc/Makefile", "include/jurassic_abi.h"]
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_current.json")
 
 
@@ -322,7 +325,7 @@ def roofline_block(workload, kms, nrays_step, steps, sum_np, shape, ab):
              "hbm_compulsory_frac": compulsory[k] * sum_np * steps / n / avg_s / HBM_PEAK}
         if pmc and k in pmc["kernels"]:
             c = pmc["kernels"][k]
-            scale = rays_per_launch / pmc["rays_per_launch"]
+            scale = rays_per_launch / c.get("rays_per_launch", pmc["rays_per_launch"])
             e["valu_insts_per_launch"] = c["SQ_INSTS_VALU"] * scale
             e["valu_issue_frac"] = c["SQ_INSTS_VALU"] * scale / avg_s / VALU_PEAK
             e["traffic"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 * scale

@@ -157,6 +157,12 @@ int  jur_formod_device(jur_model_t *m, long nr, double const *d_geom,
  *   bounds[0 .. nmodel] (optional, NULL: equal ray counts): share k = rays [bounds[k], bounds[k+1]), e.g. from
  *   jur_multi_balance when the geometry is known on the host.  d_status (optional) is int[nmodel], one word per share. */
 int  jur_multi_balance(jur_model_t const *m, long nr, double const *const geom[7], int nparts, long *bounds);
+/* The same without a model or a GPU (host arithmetic only): the estimated number of LOS points of every ray from the
+ * tracer's step sizes (ctl->rayds, ctl->raydz) and the altitude range [zmin, zmax] of the atmosphere, and the balanced
+ * boundaries from it -- what a launcher that deals a SORTED observation set to one process per GPU needs
+ * (jurassic_hip/shard.py: balanced_ranges). */
+int  jur_estimate_los_points(double rayds, double raydz, double zmin, double zmax, long nr, double const *const geom[7], double *points);
+int  jur_balance_rays(double rayds, double raydz, double zmin, double zmax, long nr, double const *const geom[7], int nparts, long *bounds);
 int  jur_models_set_atm(jur_model_t *const models[], int nmodel, atm_t const *atm);
 int  jur_formod_host_multi(jur_model_t *const models[], int nmodel, long nr, double const *const geom[7],
                            double *rad, double *tau, double *const tp[3], int *np_out);

@@ -72,12 +72,16 @@ static double ray_cost(double const *const geom[7], long i, double rayds, double
   return np < JUR_NLOS ? np : JUR_NLOS;
 }
 
+/* the estimate for nr rays, without a model or a GPU: the tracer's step sizes and the altitude range of the atmosphere */
+int jur_estimate_los_points(double rayds, double raydz, double zmin, double zmax, long nr, double const *const geom[7], double *points) {
+  if (!(rayds > 0) || !(zmax > zmin) || nr < 0 || (nr > 0 && (!geom || !points))) { jur_set_error("estimate_los_points: bad arguments"); return JUR_EINVAL; }
+  for (long i = 0; i < nr; i++) points[i] = ray_cost(geom, i, rayds, raydz, zmin, zmax);
+  return JUR_OK;
+}
+
 /* bounds[0 .. nparts]: rays [bounds[k], bounds[k+1]) go to part k; equal estimated points + a per-ray constant */
-int jur_multi_balance(jur_model_t const *m, long nr, double const *const geom[7], int nparts, long *bounds) {
-  if (!m || nr < 0 || nparts < 1 || !bounds) { jur_set_error("multi_balance: bad arguments"); return JUR_EINVAL; }
-  double rayds, raydz, zmin, zmax;
-  jur_model_cost_params(m, &rayds, &raydz, &zmin, &zmax);
-  if (!(rayds > 0)) { jur_set_error("multi_balance: RAYDS must be positive"); return JUR_EINVAL; }
+int jur_balance_rays(double rayds, double raydz, double zmin, double zmax, long nr, double const *const geom[7], int nparts, long *bounds) {
+  if (!(rayds > 0) || !(zmax > zmin) || nr < 0 || nparts < 1 || !bounds) { jur_set_error("balance_rays: bad arguments"); return JUR_EINVAL; }
   bounds[0] = 0; bounds[nparts] = nr;
   if (nparts == 1 || nr == 0) { for (int k = 1; k < nparts; k++) bounds[k] = nr; return JUR_OK; }
   double const per_ray = 8;                                /* set-up, epilogue: a ray costs something even if it is short */
@@ -91,6 +95,14 @@ int jur_multi_balance(jur_model_t const *m, long nr, double const *const geom[7]
   }
   while (k < nparts) bounds[k++] = nr;
   return JUR_OK;
+}
+
+int jur_multi_balance(jur_model_t const *m, long nr, double const *const geom[7], int nparts, long *bounds) {
+  if (!m) { jur_set_error("multi_balance: bad arguments"); return JUR_EINVAL; }
+  double rayds, raydz, zmin, zmax;
+  jur_model_cost_params(m, &rayds, &raydz, &zmin, &zmax);
+  if (!(zmax > zmin)) { jur_set_error("multi_balance: the model has no atmosphere yet (jur_model_set_atm)"); return JUR_EINVAL; }
+  return jur_balance_rays(rayds, raydz, zmin, zmax, nr, geom, nparts, bounds);
 }
 
 static int check_models(jur_model_t *const models[], int nmodel, char const *who) {

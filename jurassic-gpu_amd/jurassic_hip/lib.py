@@ -82,6 +82,8 @@ def lib():
         L.jur_model_set_ega_group.argtypes = [C.c_void_p, C.c_int]
         L.jur_model_ega_group.argtypes = [C.c_void_p]
         L.jur_multi_balance.argtypes = [C.c_void_p, C.c_long, C.POINTER(dp), C.c_int, C.POINTER(C.c_long)]
+        L.jur_estimate_los_points.argtypes = [C.c_double] * 4 + [C.c_long, C.POINTER(dp), dp]
+        L.jur_balance_rays.argtypes = [C.c_double] * 4 + [C.c_long, C.POINTER(dp), C.c_int, C.POINTER(C.c_long)]
         L.jur_models_set_atm.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
         L.jur_formod_host_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.POINTER(dp), dp, dp, C.POINTER(dp), C.POINTER(C.c_int)]
         L.jur_formod_device_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.POINTER(C.c_long)] + [C.c_void_p] * 7
@@ -408,6 +410,26 @@ def multi_balance(model, geom, nparts):
     garr = (dp * 7)(*[_p(g[k]) for k in range(7)])
     b = (C.c_long * (nparts + 1))()
     _chk(lib().jur_multi_balance(model.h, g.shape[1], garr, nparts, b))
+    return list(b)
+
+
+def estimate_los_points(ctl, atm, geom):
+    """Estimated LOS points per ray (jur_estimate_los_points): host arithmetic, no GPU."""
+    g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
+    z = np.ctypeslib.as_array(atm.z)[:atm.np]
+    garr = (dp * 7)(*[_p(g[k]) for k in range(7)])
+    out = np.zeros(g.shape[1])
+    _chk(lib().jur_estimate_los_points(ctl.rayds, ctl.raydz, float(z.min()), float(z.max()), g.shape[1], garr, _p(out)))
+    return out
+
+
+def balance_rays(ctl, atm, geom, nparts):
+    """Boundaries of nparts contiguous ray ranges with equal estimated LOS points (jur_balance_rays): no GPU."""
+    g = np.ascontiguousarray(np.asarray(geom, dtype=np.float64).T)
+    z = np.ctypeslib.as_array(atm.z)[:atm.np]
+    garr = (dp * 7)(*[_p(g[k]) for k in range(7)])
+    b = (C.c_long * (nparts + 1))()
+    _chk(lib().jur_balance_rays(ctl.rayds, ctl.raydz, float(z.min()), float(z.max()), g.shape[1], garr, nparts, b))
     return list(b)
 
 

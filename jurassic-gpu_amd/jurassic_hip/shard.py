@@ -23,6 +23,16 @@ def ray_counts(world, n):
     return [ray_range(r, world, n)[1] - ray_range(r, world, n)[0] for r in range(world)]
 
 
+def balanced_ranges(ctl, atm, geom, world):
+    """Contiguous ranges [(lo, hi)] * world of a ray set with equal estimated LINE-OF-SIGHT POINTS instead of equal ray
+    counts (a tangent-height scan in its natural order has 393 .. 122 points per ray, so equal
+    counts leave the rank with the high tangent altitudes idle half of the time).  Host arithmetic of the library
+    (jur_balance_rays: no GPU, no model); for ray sets in random order -- bench.py's -- ray_range is balanced already."""
+    from . import lib
+    b = lib.balance_rays(ctl, atm, geom, world)
+    return [(b[k], b[k + 1]) for k in range(world)]
+
+
 def gather_rows(local, counts, dst=0, group=None, out=None):
     """Gather row blocks of unequal length to `dst`.
 

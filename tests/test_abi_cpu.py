@@ -330,3 +330,29 @@ def test_kernel_register_budgets(tmp_path):
         assert len(hits) == 1, (key, list(seen))
         (vgprs, scratch), = hits.values()
         assert vgprs <= limit and scratch <= scratch_limit, (key, vgprs, scratch)
+
+
+def test_los_point_estimate_balances_a_sorted_scan(oracle):
+    """jur_estimate_los_points / jur_balance_rays (host arithmetic of the library, no GPU): the closed-form estimate of the
+    tracer's point count against the oracle's ACTUAL count for a tangent-height scan, a nadir sweep, rays that miss the
+    atmosphere and an observer inside it; shares cut from it carry equal actual points within 6 % where equal ray counts
+    are off by a factor of two (what jur_formod_host_multi and shard.balanced_ranges deal by)."""
+    from jurassic_hip import lib, shard
+    g = synth.limb_geometry(1200, scan=True)
+    extra = np.array([[0, 780.0, 0, 0, 95.0, 0, 20.0], [0, 30.0, 0, 0, 5.0, 0, 3.0], [0, 780.0, 0, 0, -0.005, 0, 27.0]])
+    geom = np.vstack([g, synth.nadir_geometry(150, seed=3), extra])
+    case = common.limb_case(geom=geom)
+    ref = oracle.formod_rays(case.ctl, case.atm, case.oracle_tables(oracle), case.geom)["np"].astype(float)
+    est = lib.estimate_los_points(case.ctl, case.atm, case.geom)
+    assert est.shape == ref.shape and np.all(est >= 0) and est[1350] == 0 and ref[1350] == 0          # the ray that never enters
+    live = ref > 0
+    rel = np.abs(est[live] - ref[live]) / ref[live]
+    print("estimate against the tracer's count: mean %.3f, worst %.3f; totals %.0f / %.0f" % (rel.mean(), rel.max(), est.sum(), ref.sum()))
+    assert rel.mean() < 0.03 and rel.max() < 0.15 and abs(est.sum() - ref.sum()) < 0.02 * ref.sum()
+    for world in (2, 3, 8):
+        ranges = shard.balanced_ranges(case.ctl, case.atm, case.geom, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == len(geom) and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        pts = [ref[lo:hi].sum() for lo, hi in ranges]
+        eq = [ref[slice(*shard.ray_range(r, world, len(geom)))].sum() for r in range(world)]
+        assert max(pts) <= 1.06 * min(pts) + 400, (world, pts)        # (refraction lengthens the low rays a little: a systematic 5 %)
+        assert max(eq) > 1.5 * min(eq), eq

@@ -261,3 +261,34 @@ def test_tracer_with_four_lanes_per_ray(hip):
             m.close()
     finally:
         hip.tune_trace(0)
+
+
+def test_batched_call_in_a_graph(hip):
+    """The batched kernels (ray sort, quad-lane tracer, look-up, radiance update -- no fused kernel) captured into a HIP
+    graph after jur_model_reserve and replayed on new inputs: a call that fits the workspace never waits for the host."""
+    import torch
+    case = common.limb_case(geom=synth.limb_geometry(5000, seed=12, nprofiles=2), nprofiles=2)
+    model = hip.Model(case.ctl, case.lib_tables())
+    model.set_atm(case.atm)
+    model.set_pencil(0)
+    dev = torch.device("cuda", 0)
+    nr, nd = len(case.geom), case.ctl.nd
+    d_geom = torch.from_numpy(np.ascontiguousarray(case.geom.T)).to(dev)
+    d_rad = torch.zeros((nr, nd), dtype=torch.float64, device=dev)
+    d_tau = torch.zeros((nr, nd), dtype=torch.float64, device=dev)
+    d_tp = torch.zeros((3, nr), dtype=torch.float64, device=dev)
+    d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+    model.reserve(nr)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        d_rad.zero_()
+        model.formod_device(nr, d_geom.data_ptr(), d_rad.data_ptr(), d_tau.data_ptr(), d_tp.data_ptr(), 0,
+                            d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for seed in (12, 13):
+        geom = synth.limb_geometry(nr, seed=seed, nprofiles=2)
+        d_geom.copy_(torch.from_numpy(np.ascontiguousarray(geom.T)))
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = model.formod_host(geom)
+        assert same_bits(d_rad.cpu().numpy(), ref["rad"]) and same_bits(d_tau.cpu().numpy(), ref["tau"]) and int(d_st.item()) == 0
+    model.close()

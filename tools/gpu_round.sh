@@ -32,7 +32,7 @@ for w in $WHAT; do
            PMC_SHORT=1 step pmc_nadir 900 bash tools/pmc_profile.sh gpurun_out/${TAG}_pmc_nadir --workload nadir_1e5 --steps 1 --warmup 0
            step pmc_nadir_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_nadir nadir_1e5 100000 gpurun_out/${TAG}_pmc_current.json ;;
     pmcairs) PMC_SHORT=1 step pmc_airs 1100 bash tools/pmc_profile.sh gpurun_out/${TAG}_pmc_airs --workload airs_2378_sharded --steps 1 --warmup 0
-           step pmc_airs_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_airs airs_2378_sharded 11364 gpurun_out/${TAG}_pmc_current.json ;;
+           step pmc_airs_summary 60 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_airs airs_2378_sharded 125000 gpurun_out/${TAG}_pmc_current.json ;;
     lanesmode) for md in "JUR_NO_ZERO_COPY=1" "GPU_MAX_HW_QUEUES=8" "JUR_PENCIL_RAYS=0"; do
              TAIL=6 EXTRA_ENV="env $md" CALLS=16 step lanesmode_${md%%=*} 300 bash tools/run_lanes_bench.sh
            done ;;

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc CSV passes per kernel (mean counter value per dispatch) and file the result as
 profiles/pmc_current.json, the counter summary bench.py's roofline block reads.
 
-usage: pmc_summary.py <dir with the passes> <workload> <rays per launch> [out.json]
+usage: pmc_summary.py <dir with the passes> <workload> <rays per step> [out.json]
 
 The summary records the sha256 of the kernel sources (bench.kernel_source_sha) it was measured on; bench.py
 refuses a summary whose sha differs from the sources it runs.  An existing out.json measured on the same sources
@@ -33,6 +33,11 @@ for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), rec
 kernels = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 for k, d in kernels.items():
     d["dispatches"] = max(len(v) for v in agg[k].values())
+# a kernel launched several times per step (chunked workloads: the look-up and the radiance update of the many-channel
+# set) covers fewer rays per launch than one launched once: rays per launch per kernel, from the dispatch counts
+steps = min(d["dispatches"] for d in kernels.values())
+for k, d in kernels.items():
+    d["rays_per_launch"] = rays * steps / d["dispatches"]
 sha = bench.kernel_source_sha()
 doc = {"kernel_source_sha256": sha, "workloads": {}}
 if os.path.exists(out_path):
