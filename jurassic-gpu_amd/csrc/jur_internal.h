@@ -15,6 +15,8 @@ typedef struct { float u, eps; } jur_ue_t;
 /* slopes of the bracket [entry i, entry i+1] of a curve, formed on the device once per model from the fp32 entries
  * (strictly increasing tables only): what get_u and get_eps multiply with instead of dividing by the bracket width */
 typedef struct { double du_de, de_du; } __attribute__((aligned(16))) jur_sl_t;
+/* bracket [entry i, entry i+1] of a curve in one record: the two entries as stored and both slopes (strict tables) */
+typedef struct { float u0, e0, u1, e1; double du_de, de_du; } __attribute__((aligned(32))) jur_rec_t;
 /* 16-byte descriptors: one load brings the axis value together with the extent
  * and the offset of the next level of the hierarchy. */
 typedef struct { double p; int nt; int c0; } jur_lvl_t;   /* pressure level: nt curves from curve c0 */
@@ -72,6 +74,7 @@ typedef struct {
   jur_crv_t const *crv;
   jur_ue_t const *ue;
   jur_sl_t const *sl;           /* [entries] bracket slopes, indexed like ue; NULL unless strict_tables            */
+  jur_rec_t const *rec;         /* [entries] bracket records (entries i, i+1 and the slopes of [i, i+1]), or NULL      */
   long long const *pair_e0;     /* [ng*nd] first entry of every pair in ue (64 bits: a full-extent many-channel set --
                                    2378 channels x 3 gases x 40 x 30 x 304 = 2.6e9 entries -- is addressed as
                                    wave-uniform pair base + 32-bit offset inside the pair)                        */
@@ -132,6 +135,7 @@ void jurk_tune_trace(int lanes);
 int jurk_launch_cg(jur_view_t const *v, jur_chunk_t const *c, double *cgp, double *cgt, double *cgu, void *stream);
 /* bracket slopes of all n table entries (the last entry of a curve gets a value nobody reads) */
 int jurk_fill_slopes(jur_ue_t const *ue, jur_sl_t *sl, long long n, void *stream);
+int jurk_fill_records(jur_ue_t const *ue, jur_sl_t const *sl, jur_rec_t *rec, long long n, void *stream);   /* ue, sl: n + 1 entries */
 /* order rays by their geometric tangent altitude: fills order[nr]; `tmp` is a
  * device scratch of jurk_sort_tmp_bytes(nr) bytes */
 long jurk_sort_tmp_bytes(long nr);

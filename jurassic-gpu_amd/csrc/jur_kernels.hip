@@ -873,6 +873,97 @@ __device__ __forceinline__ void seek_curve_keys(void const *__restrict__ ue, uns
   }
 }
 
+// ---- bracket records (round 4) ---------------------------------------------------------------------------------
+// Everything the strict-table look-up needs of bracket [i, i+1] of a curve in ONE 32-byte record, indexed like the
+// entries: the four fp32 values of the two entries and the two slopes.  Rounds 1 - 3 fetched them from two arrays in
+// three accesses (16-byte entry pair, 8-byte slope for get_u, 8-byte slope for get_eps): two to three cache lines and
+// three uniformity tests per curve where this is one line (records never straddle one) and one test -- and what the
+// round-4 experiments say holds the kernel is the number of table lines a wavefront touches per segment
+// (profiles/r04_ega_*_experiment.json).  A search that leaves its bracket by one step fetches the neighbouring record,
+// which IS the new bracket (keys and slopes); get_eps finds itself in get_u's bracket two times out of three and
+// fetches nothing.  Same operations on the same operands as the separate arrays: the same doubles.
+struct __attribute__((aligned(32))) Rec { float u0, e0, u1, e1; double du_de, de_du; };
+static_assert(sizeof(Rec) == sizeof(jur_rec_t) && sizeof(Rec) == 32, "layout");
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ Rec rec_from(f32x8 const v) {
+  Rec r;
+  r.u0 = v.s0; r.e0 = v.s1; r.u1 = v.s2; r.e1 = v.s3;
+  r.du_de = __hiloint2double(__float_as_int(v.s5), __float_as_int(v.s4));
+  r.de_du = __hiloint2double(__float_as_int(v.s7), __float_as_int(v.s6));
+  return r;
+}
+__device__ __forceinline__ Rec ld_rec(void const *__restrict__ rec, unsigned idx) { return ldg<Rec>(rec, idx); }
+__device__ __forceinline__ Rec ld_rec_u(void const *__restrict__ rec, unsigned idx) {     // ... once per wavefront where all lanes agree
+  unsigned i0;
+  if (all_lanes_at(idx, i0)) return rec_from(ld_scalar<f32x8>(rec, i0 * 32u));
+  return ld_rec(rec, idx);
+}
+__device__ __forceinline__ void ld_rec2(void const *__restrict__ rec, unsigned ia, unsigned ib, Rec &a, Rec &b) {
+  unsigned fa, fb;
+  bool const ua = all_lanes_at(ia, fa), ub = all_lanes_at(ib, fb);
+  if (ua & ub) {
+    f32x8 const x = ld_scalar<f32x8>(rec, fa * 32u), y = ld_scalar<f32x8>(rec, fb * 32u);
+    a = rec_from(x); b = rec_from(y);
+    return;
+  }
+  a = ld_rec(rec, ia);
+  b = ld_rec(rec, ib);
+}
+// key of ENTRY idx (the lower end of record idx), as a double, for the far moves of a search
+template <bool ON_EPS>
+__device__ __forceinline__ double rec_key(void const *__restrict__ rec, unsigned idx) {
+  return (double)*reinterpret_cast<float const *>(static_cast<char const *>(rec) + (size_t)(idx * 32u + (ON_EPS ? 4u : 0u)));
+}
+// seek_curve_keys on records: bracket i of curve [e0, e0 + n) with its record r and its keys ka, kb as doubles (formed
+// here unless the caller HAS them).  Same probes, same bracket.
+template <bool ON_EPS, bool HAVE>
+__device__ __forceinline__ void seek_rec(void const *__restrict__ rec, unsigned e0, int n, double x, int &i, Rec &r, double &ka, double &kb) {
+  if (!HAVE) { ka = cvt_keep(ON_EPS ? r.e0 : r.u0); kb = cvt_keep(ON_EPS ? r.e1 : r.u1); }
+  bool const up = x >= kb, down = x < ka;
+  if (!(up | down)) return;
+  if (up) {
+    if (i >= n - 2) return;
+    Rec const c = ld_rec_u(rec, e0 + i + 1);           // bracket [i+1, i+2]
+    double const kc = cvt_keep(ON_EPS ? c.e1 : c.u1);
+    if (i + 2 >= n - 1 || kc > x) { ++i; r = c; ka = kb; kb = kc; return; }
+    int lo = i + 2, hi, step = 2;
+    for (;;) {
+      hi = lo + step;
+      if (hi >= n - 1) { hi = n - 1; break; }
+      if (rec_key<ON_EPS>(rec, e0 + hi) > x) break;
+      lo = hi;
+      step <<= 1;
+    }
+    while (hi > lo + 1) {
+      int const mid = (lo + hi) >> 1;
+      if (rec_key<ON_EPS>(rec, e0 + mid) > x) hi = mid; else lo = mid;
+    }
+    i = lo;
+    r = ld_rec(rec, e0 + i);                              // (each far-move branch ends in its own reload)
+    ka = cvt_keep(ON_EPS ? r.e0 : r.u0); kb = cvt_keep(ON_EPS ? r.e1 : r.u1);
+  } else {
+    if (i <= 0) return;
+    Rec const c = ld_rec_u(rec, e0 + i - 1);           // bracket [i-1, i]
+    double const kc = cvt_keep(ON_EPS ? c.e0 : c.u0);
+    if (i - 1 <= 0 || kc <= x) { --i; r = c; kb = ka; ka = kc; return; }
+    int hi = i - 1, lo, step = 2;
+    for (;;) {
+      lo = hi - step;
+      if (lo <= 0) { lo = 0; break; }
+      if (rec_key<ON_EPS>(rec, e0 + lo) <= x) break;
+      hi = lo;
+      step <<= 1;
+    }
+    while (hi > lo + 1) {
+      int const mid = (lo + hi) >> 1;
+      if (rec_key<ON_EPS>(rec, e0 + mid) > x) hi = mid; else lo = mid;
+    }
+    i = lo;
+    r = ld_rec(rec, e0 + i);
+    ka = cvt_keep(ON_EPS ? r.e0 : r.u0); kb = cvt_keep(ON_EPS ? r.e1 : r.u1);
+  }
+}
+
 // Table descriptors of ONE (gas, channel) pair as the look-up sees them: read from global memory, or
 // from a copy the workgroup has staged in LDS (every lane of the workgroup works on the same pair; LDS
 // reads are counted by lgkmcnt and stay out of the queue of the curve gathers).
@@ -896,6 +987,7 @@ struct PairDesc {
   // 1/(p[i+1] - p[i]) and 1/(T[k+1] - T[k]): formed by the staging loop (LDS), or here with the same division --
   // the same doubles either way (the fused kernel reads its descriptors through L1 and has no staged copy)
   unsigned rp_off, rt_off;     // byte offsets of the two reciprocal arrays in the LDS block
+  void const *recb = nullptr;  // bracket records of the pair (set by the kernels that use them)
   __device__ __forceinline__ double rp(int i) const {
     if constexpr (LDS) return reinterpret_cast<double const *>(jur_lds + rp_off)[i];
     else return 1. / (lvl(i + 1).p - lvl(i).p);
@@ -971,10 +1063,11 @@ __device__ __forceinline__ double ega_eps_exact(jur_view_t const &v, jur_int2 co
 // RCPB is the strict-table arithmetic described at lip_slope; with PATH the function returns the NEW path
 // transmittance (1 - eps_t, or tau where the reference's look-up answers 1) instead of the segment's
 // transmittance (1 - eps_t) / tau -- what the kernels carry and write; the known-answer hook asks for the quotient.
-template <bool LDS, bool RCPB, bool PATH = false>
+template <bool LDS, bool RCPB, bool PATH = false, bool REC = false>
 __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 const pr, PairDesc<LDS> const &D, double tau, double t,
                                                double u, double p, unsigned &br, unsigned &ia, unsigned &ib) {
   static_assert(RCPB || !PATH, "only the strict-table arithmetic carries the path transmittance itself");
+  static_assert(RCPB || !REC, "bracket records hold the slopes of the strict-table arithmetic");
   double const one = PATH ? tau : 1.;          // the look-up's "no change" answer
   if (tau < 1e-9) return 0.;
   if (pr.a < 2) return one;
@@ -1016,6 +1109,21 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
     Ue a[2], b[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) i[k] = min(i[k], n[k] - 2);
+    double x[2], ec[2];
+    if constexpr (REC) {   // one record per bracket: keys and both slopes in one fetch
+      Rec r[2];
+      ld_rec2(D.recb, e0[0] + i[0], e0[1] + i[1], r[0], r[1]);      // both fetches in flight, then one curve after the other
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        double ka, kb;
+        seek_rec<true, false>(D.recb, e0[k], n[k], eps, i[k], r[k], ka, kb);
+        double const ya = cvt_keep(r[k].u0);
+        x[k] = lip_slope(ka, ya, r[k].du_de, eps) + u;
+        ka = ya; kb = cvt_keep(r[k].u1);
+        seek_rec<false, true>(D.recb, e0[k], n[k], x[k], i[k], r[k], ka, kb);
+        ec[k] = c01_num(lip_slope(ka, (double)r[k].e0, r[k].de_du, x[k]));
+      }
+    } else
     if constexpr (RCPB) ld_pair2(ueb, e0[0] + i[0], e0[1] + i[1], a[0], b[0], a[1], b[1]);
     else {
 #pragma unroll
@@ -1024,8 +1132,8 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
     // get_u (jr_common.h:179-185): u at which the curve reaches eps; get_eps (:156-177): the curve's
     // emissivity at that u plus the segment's column -- the column only grows, so the second search
     // starts where the first ended
-    double x[2], ec[2];
-    if constexpr (RCPB) {  // the keys of each bracket as doubles from the search that tests them to the interpolation
+    if constexpr (REC) {
+    } else if constexpr (RCPB) {  // the keys of each bracket as doubles from the search that tests them to the interpolation
       double ka[2], kb[2];
 #pragma unroll
       for (int k = 0; k < 2; k++) seek_curve_keys<true, false>(ueb, e0[k], n[k], eps, i[k], a[k], b[k], ka[k], kb[k]);
@@ -1320,8 +1428,11 @@ __device__ __forceinline__ void stage_pair(jur_view_t const &v, jur_int2 const p
 // from that XCD's L2): b -> xcd = b % 8, s = b / 8, ray block = (s / npair) * 8 + xcd,
 // pair = s % npair.  Placement only affects speed.
 // ---------------------------------------------------------------------------------------
-template <bool WARM, bool LDS, bool RCPB>
-__global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
+#ifndef JUR_REC_WAVES
+#define JUR_REC_WAVES 7
+#endif
+template <bool WARM, bool LDS, bool RCPB, bool REC = false>
+__global__ __launch_bounds__(256, REC ? JUR_REC_WAVES : 5) void jur_ega_kernel(jur_view_t v, jur_chunk_t c, int nrb) {
   static_assert(WARM || !RCPB, "reciprocal widths need strictly increasing axes");
   int const npair = v.nd * v.ng;
   BlockItem const bi = xcd_block_item((int)blockIdx.x, nrb, npair);
@@ -1333,6 +1444,7 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
   jur_int2 const pd = v.pair[pair_idx];
   if (pd.a < 2) return;                          // no table: transmittance 1, the combine kernel knows
   PairDesc<LDS> D{v.lvl, v.crv, v.ue + v.pair_e0[pair_idx], v.sl + v.pair_e0[pair_idx], (unsigned)pd.b, 0u, 0u, 0u};
+  if constexpr (REC) D.recb = v.rec + v.pair_e0[pair_idx];
   stage_pair<LDS, RCPB>(v, pd, D);
   if (r >= c.n) return;
   // the workspaces are addressed as (wave-uniform pointer into this wavefront's tile) + lane offset
@@ -1365,7 +1477,7 @@ __global__ __launch_bounds__(256, 5) void jur_ega_kernel(jur_view_t v, jur_chunk
     } else { p = ldg<double>(los_p + o, lane); t = ldg<double>(los_t + o, lane); }
     double const u = ldg<double>(los_u + o, lane);
     // what is carried and written is the gas's transmittance of the path up to and including this segment
-    if constexpr (RCPB) tau_path = ega_eps_warm<LDS, true, true>(v, pd, D, tau_path, t, u, p, br, ia, ib);
+    if constexpr (RCPB) tau_path = ega_eps_warm<LDS, true, true, REC>(v, pd, D, tau_path, t, u, p, br, ia, ib);
     else if constexpr (WARM) tau_path *= ega_eps_warm<LDS, false>(v, pd, D, tau_path, t, u, p, br, ia, ib);
     else tau_path *= ega_eps_exact<LDS>(v, pd, D, tau_path, t, u, p);
     *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)(lane * 8u)) = tau_path;
@@ -2090,6 +2202,13 @@ __global__ __launch_bounds__(256) void jur_cg_kernel(jur_view_t v, jur_chunk_t c
 // Bracket slopes of the emissivity curves, once per model: entry j gets the slopes of [entry j, entry j+1] in both
 // directions, formed from the fp32 entries with fp64 differences and IEEE divisions.  The last entry of a curve pairs
 // with the first of the next one; the look-up never reads that slot (its bracket index ends at nu - 2).
+// bracket records from the entries and their slopes (entry i and i + 1, slopes of bracket [i, i+1]); once per model
+__global__ __launch_bounds__(256) void jur_records_kernel(long long n, jur_ue_t const *__restrict__ ue, jur_sl_t const *__restrict__ sl,
+                                                          jur_rec_t *__restrict__ rec) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    rec[i] = jur_rec_t{ue[i].u, ue[i].eps, ue[i + 1].u, ue[i + 1].eps, sl[i].du_de, sl[i].de_du};
+}
+
 __global__ __launch_bounds__(256) void jur_slopes_kernel(long long n, jur_ue_t const *__restrict__ ue, jur_sl_t *__restrict__ sl) {
   for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j + 1 < n; j += (long long)gridDim.x * blockDim.x) {
     double const du = (double)ue[j + 1].u - (double)ue[j].u, de = (double)ue[j + 1].eps - (double)ue[j].eps;
@@ -2276,16 +2395,17 @@ __global__ __launch_bounds__(128) void jur_intpol_kernel(IntpolArgs a) {
 // chain != 0: ONE lane walks the n inputs in order and carries the warm-start state (br, ia, ib) from element
 // to element as jur_ega_kernel carries it from segment to segment -- the result of a look-up must not depend on
 // where the previous one left the brackets.
-template <bool WARM, bool LDS, bool RCPB>
+template <bool WARM, bool LDS, bool RCPB, bool REC = false>
 __global__ __launch_bounds__(256) void jur_kat_ega_kernel(jur_view_t v, int g, int d, long n, double const *__restrict__ tau,
                                                           double const *__restrict__ t, double const *__restrict__ u,
                                                           double const *__restrict__ p, int chain, double *__restrict__ out) {
   jur_int2 const pd = v.pair[g * v.nd + d];
   PairDesc<LDS> D{v.lvl, v.crv, v.ue + v.pair_e0[g * v.nd + d], v.sl + v.pair_e0[g * v.nd + d], (unsigned)pd.b, 0u, 0u, 0u};
+  if constexpr (REC) D.recb = v.rec + v.pair_e0[g * v.nd + d];
   if (pd.a >= 2) stage_pair<LDS, RCPB>(v, pd, D);       // uniform branch; stage_pair ends in a barrier
   unsigned br = 0, ia = 0, ib = 0;
   auto one = [&](long i) {
-    if constexpr (WARM) out[i] = ega_eps_warm<LDS, RCPB, false>(v, pd, D, tau[i], t[i], u[i], p[i], br, ia, ib);
+    if constexpr (WARM) out[i] = ega_eps_warm<LDS, RCPB, false, REC>(v, pd, D, tau[i], t[i], u[i], p[i], br, ia, ib);
     else out[i] = ega_eps_exact<LDS>(v, pd, D, tau[i], t[i], u[i], p[i]);
   };
   if (chain) {
@@ -2412,7 +2532,8 @@ extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *
   bool const use_lds = v->max_pair_curves > 0 && lds <= 48 * 1024 && !getenv("JUR_EGA_NO_LDS");
   bool const rcpb = use_lds && v->fast_arith;
   if (v->sorted_tables) {
-    if (rcpb) hipLaunchKernelGGL((jur_ega_kernel<true, true, true>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
+    if (rcpb && v->rec) hipLaunchKernelGGL((jur_ega_kernel<true, true, true, true>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
+    else if (rcpb) hipLaunchKernelGGL((jur_ega_kernel<true, true, true>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
     else if (use_lds) hipLaunchKernelGGL((jur_ega_kernel<true, true, false>), dim3(grid), dim3(block), lds, s, *v, *c, nrb);
     else hipLaunchKernelGGL((jur_ega_kernel<true, false, false>), dim3(grid), dim3(block), 0, s, *v, *c, nrb);
   } else {
@@ -2540,6 +2661,7 @@ extern "C" int jurk_kat_ega(jur_view_t const *v, int g, int d, long n, double co
     else hipLaunchKernelGGL((jur_kat_ega_kernel<false, false, false>), grid, block, 0, s, *v, g, d, n, tau, t, u, p, chain, out);
   } else if (mode == 1) hipLaunchKernelGGL((jur_kat_ega_kernel<true, false, false>), grid, block, 0, s, *v, g, d, n, tau, t, u, p, chain, out);
   else if (mode == 2) hipLaunchKernelGGL((jur_kat_ega_kernel<true, true, false>), grid, block, lds, s, *v, g, d, n, tau, t, u, p, chain, out);
+  else if (v->rec) hipLaunchKernelGGL((jur_kat_ega_kernel<true, true, true, true>), grid, block, lds, s, *v, g, d, n, tau, t, u, p, chain, out);   // what the batched kernel runs
   else hipLaunchKernelGGL((jur_kat_ega_kernel<true, true, true>), grid, block, lds, s, *v, g, d, n, tau, t, u, p, chain, out);
   return (int)hipGetLastError();
 }
@@ -2606,6 +2728,12 @@ extern "C" int jurk_launch_pencil(jur_view_t const *v, jur_chunk_t const *c, int
     if (quad) hipLaunchKernelGGL((jur_pencil_kernel<false, true>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
     else hipLaunchKernelGGL((jur_pencil_kernel<false, false>), grid, block, (size_t)lds_all, s, *v, *c, RB, NE, NC, atm_cap);
   }
+  return (int)hipGetLastError();
+}
+
+extern "C" int jurk_fill_records(jur_ue_t const *ue, jur_sl_t const *sl, jur_rec_t *rec, long long n, void *stream) {
+  long long const nb = (n + 255) / 256;
+  hipLaunchKernelGGL(jur_records_kernel, dim3((unsigned)(nb < 65536 ? (nb > 0 ? nb : 1) : 65536)), dim3(256), 0, (hipStream_t)stream, n, ue, sl, rec);
   return (int)hipGetLastError();
 }
 

@@ -32,7 +32,7 @@ struct jur_model {
   jur_view_t view;              /* device pointers                               */
   long table_bytes;
   /* device allocations owned by the model */
-  void *d_chan, *d_sr, *d_pair, *d_pair_e0, *d_lvl, *d_crv, *d_ue, *d_sl, *d_items;
+  void *d_chan, *d_sr, *d_pair, *d_pair_e0, *d_lvl, *d_crv, *d_ue, *d_sl, *d_items, *d_rec;
   int arith;                    /* JUR_ARITH_*                                   */
   int *grid_cls;                /* [ng*nd] grid class of every pair (strict tables), see jur_model_set_ega_group */
   unsigned char *grid_all;
@@ -208,6 +208,16 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
       rc = JUR_EHIP;
     }
   }
+  if (!rc && fl.strict && !getenv("JUR_EGA_NO_REC")) {   /* bracket records: entries i, i+1 and both slopes in 32 bytes (what the
+                                                            batched look-up kernel reads; JUR_EGA_NO_REC: the two arrays, A/B) */
+    rc = upload(&m->d_rec, NULL, sizeof(jur_rec_t) * (fl.nentry + 2));
+    if (!rc && (jurk_fill_records((jur_ue_t const *)m->d_ue, (jur_sl_t const *)m->d_sl, (jur_rec_t *)m->d_rec, fl.nentry + 1, NULL) ||
+                hipStreamSynchronize(NULL) != hipSuccess)) {
+      jur_set_error("cannot form the bracket records of the tables");
+      rc = JUR_EHIP;
+    }
+    v->rec = (jur_rec_t const *)m->d_rec;
+  }
   if (!rc && fl.strict && npair > 0) {   /* which channels of a gas stand on one (p, T) grid: jur_model_set_ega_group */
     m->grid_cls = (int *)malloc(sizeof(int) * npair);
     m->grid_all = (unsigned char *)malloc(npair);
@@ -221,7 +231,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   v->sorted_tables = fl.sorted;
   v->strict_tables = fl.strict;
   v->max_pair_curves = fl.max_pair_curves;
-  m->table_bytes = (long)((sizeof(jur_ue_t) + (fl.strict ? sizeof(jur_sl_t) : 0)) * fl.nentry + 16 * fl.ncurve + 16 * fl.nlevel + 8 * npair);
+  m->table_bytes = (long)((sizeof(jur_ue_t) + (fl.strict ? sizeof(jur_sl_t) : 0) + (m->d_rec ? sizeof(jur_rec_t) : 0)) * fl.nentry + 16 * fl.ncurve + 16 * fl.nlevel + 8 * npair);
   jur_flat_free(&fl);
   if (rc) { jur_model_destroy(m); return rc; }
   v->chan = (jur_chan_t const *)m->d_chan;
@@ -335,8 +345,8 @@ int jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device)
 void jur_model_destroy(jur_model_t *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
-  if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_pair_e0 = m->d_lvl = m->d_crv = m->d_ue = m->d_sl = m->d_items = NULL;
-  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_pair_e0, m->d_lvl, m->d_crv, m->d_ue, m->d_sl, m->d_items, m->d_atm, m->d_order, m->d_sort_tmp,
+  if (m->shared_tables) m->d_chan = m->d_sr = m->d_pair = m->d_pair_e0 = m->d_lvl = m->d_crv = m->d_ue = m->d_sl = m->d_items = m->d_rec = NULL;
+  void *ptrs[] = {m->d_chan, m->d_sr, m->d_pair, m->d_pair_e0, m->d_lvl, m->d_crv, m->d_ue, m->d_sl, m->d_items, m->d_rec, m->d_atm, m->d_order, m->d_sort_tmp,
                   m->d_los, m->d_eps, m->d_np, m->d_tsurf, m->d_status, m->d_io, m->d_io_np, m->d_fov, m->d_kq};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++)
     if (ptrs[i]) (void)hipFree(ptrs[i]);
