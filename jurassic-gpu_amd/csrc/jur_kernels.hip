@@ -916,14 +916,14 @@ __device__ __forceinline__ double rec_key(void const *__restrict__ rec, unsigned
 }
 // seek_curve_keys on records: bracket i of curve [e0, e0 + n) with its record r and its keys ka, kb as doubles (formed
 // here unless the caller HAS them).  Same probes, same bracket.
-template <bool ON_EPS, bool HAVE>
+template <bool ON_EPS, bool HAVE, bool SCALAR = true>      // SCALAR: try the scalar cache for the neighbouring record (lanes = neighbouring rays)
 __device__ __forceinline__ void seek_rec(void const *__restrict__ rec, unsigned e0, int n, double x, int &i, Rec &r, double &ka, double &kb) {
   if (!HAVE) { ka = cvt_keep(ON_EPS ? r.e0 : r.u0); kb = cvt_keep(ON_EPS ? r.e1 : r.u1); }
   bool const up = x >= kb, down = x < ka;
   if (!(up | down)) return;
   if (up) {
     if (i >= n - 2) return;
-    Rec const c = ld_rec_u(rec, e0 + i + 1);           // bracket [i+1, i+2]
+    Rec const c = SCALAR ? ld_rec_u(rec, e0 + i + 1) : ld_rec(rec, e0 + i + 1);           // bracket [i+1, i+2]
     double const kc = cvt_keep(ON_EPS ? c.e1 : c.u1);
     if (i + 2 >= n - 1 || kc > x) { ++i; r = c; ka = kb; kb = kc; return; }
     int lo = i + 2, hi, step = 2;
@@ -943,7 +943,7 @@ __device__ __forceinline__ void seek_rec(void const *__restrict__ rec, unsigned 
     ka = cvt_keep(ON_EPS ? r.e0 : r.u0); kb = cvt_keep(ON_EPS ? r.e1 : r.u1);
   } else {
     if (i <= 0) return;
-    Rec const c = ld_rec_u(rec, e0 + i - 1);           // bracket [i-1, i]
+    Rec const c = SCALAR ? ld_rec_u(rec, e0 + i - 1) : ld_rec(rec, e0 + i - 1);           // bracket [i-1, i]
     double const kc = cvt_keep(ON_EPS ? c.e0 : c.u0);
     if (i - 1 <= 0 || kc <= x) { --i; r = c; kb = ka; ka = kc; return; }
     int hi = i - 1, lo, step = 2;
@@ -1220,10 +1220,26 @@ __device__ __forceinline__ double ega_eps_warm_quad(jur_view_t const &v, jur_int
   int const n = mine.nu;
   int i = min((int)ix, n - 2);
   Ue a, b;
-  ld_pair(ueb, e0 + i, a, b);
+  if (!(FAST && D.recb)) ld_pair(ueb, e0 + i, a, b);
   double const eps = 1 - tau;
   if constexpr (FAST) {
     bool const nan_in = (tau != tau || t != t || u != u || p != p);   // as ega_eps_warm: min/max clamps below
+    if (D.recb) {   // bracket records (round 4): one fetch for the curve's keys and both slopes -- the same doubles
+      Rec r = ld_rec(D.recb, e0 + i);
+      double ka, kb;
+      seek_rec<true, false, false>(D.recb, e0, n, eps, i, r, ka, kb);
+      double const ya = (double)r.u0;
+      double const x = lip_slope(ka, ya, r.du_de, eps) + u;
+      ka = ya; kb = (double)r.u1;
+      seek_rec<false, true, false>(D.recb, e0, n, x, i, r, ka, kb);
+      double const ec = c01_num(lip_slope(ka, (double)r.e0, r.de_du, x));
+      ix = (unsigned)i;
+      double const ec0 = quad_bcast<0>(ec), ec1 = quad_bcast<1>(ec), ec2 = quad_bcast<2>(ec), ec3 = quad_bcast<3>(ec);
+      double const eps_p0 = c01_num(lip_mulr(c00.t, ec0, ec1, t, 1. / (c01_.t - c00.t)));
+      double const eps_p1 = c01_num(lip_mulr(c10.t, ec2, ec3, t, 1. / (c11.t - c10.t)));
+      double const tau_new = 1. - c01_num(lip_mulr(l0.p, eps_p0, eps_p1, p, 1. / (l1.p - l0.p)));
+      return nan_in ? __builtin_nan("") : tau_new;
+    }
     seek_curve<true>(ueb, e0, n, eps, i, a, b);
     double const x = lip_slope((double)a.eps, (double)a.u, ld_slope<0>(D.slb, e0 + i), eps) + u;
     seek_curve<false>(ueb, e0, n, x, i, a, b);
@@ -2074,6 +2090,7 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
         D.l0 = (unsigned)pd.b;
         D.ueb = v.ue + v.pair_e0[g * nd + d];
         D.slb = v.sl + v.pair_e0[g * nd + d];      // only read by the strict-table arithmetic, where v.sl is set
+        D.recb = (v.fast_arith && v.rec) ? static_cast<void const *>(v.rec + v.pair_e0[g * nd + d]) : nullptr;
         double const p = slot[JUR_F_P * RB + r], t = slot[JUR_F_T * RB + r], u = slot[(JUR_F_K + v.nw + g) * RB + r];
         double const tau_path = st_tau[e];
         double tau_new;                                            // the gas's path transmittance after this segment
@@ -2084,7 +2101,8 @@ __global__ __launch_bounds__(1024) void jur_pencil_kernel(jur_view_t v, jur_chun
           st_br[e] = br; st_ix[4 * e + (lane & 3)] = ix;
         } else if constexpr (WARM) {
           unsigned br = st_br[e], ia = st_ix[4 * e], ib = st_ix[4 * e + 1];
-          if (v.fast_arith) tau_new = ega_eps_warm<false, true, true>(v, pd, D, tau_path, t, u, p, br, ia, ib);
+          if (v.fast_arith && v.rec) tau_new = ega_eps_warm<false, true, true, true>(v, pd, D, tau_path, t, u, p, br, ia, ib);
+          else if (v.fast_arith) tau_new = ega_eps_warm<false, true, true>(v, pd, D, tau_path, t, u, p, br, ia, ib);
           else tau_new = tau_path * ega_eps_warm<false, false>(v, pd, D, tau_path, t, u, p, br, ia, ib);
           st_br[e] = br; st_ix[4 * e] = ia; st_ix[4 * e + 1] = ib;
         } else tau_new = tau_path * ega_eps_exact<false>(v, pd, D, tau_path, t, u, p);
