@@ -919,9 +919,10 @@ __device__ __forceinline__ double rec_key(void const *__restrict__ rec, unsigned
 template <bool ON_EPS, bool HAVE, bool SCALAR = true>      // SCALAR: try the scalar cache for the neighbouring record (lanes = neighbouring rays)
 __device__ __forceinline__ void seek_rec(void const *__restrict__ rec, unsigned e0, int n, double x, int &i, Rec &r, double &ka, double &kb) {
   if (!HAVE) { ka = cvt_keep(ON_EPS ? r.e0 : r.u0); kb = cvt_keep(ON_EPS ? r.e1 : r.u1); }
-  bool const up = x >= kb, down = x < ka;
-  if (!(up | down)) return;
-  if (up) {
+  // (two comparisons on the way that nearly every call takes; written as `up = x >= kb, down = x < ka` the compiler adds
+  // the NaN-safe complement of `up` for the branch below to them)
+  if ((x >= ka) & (x < kb)) return;
+  if (x >= kb) {
     if (i >= n - 2) return;
     Rec const c = SCALAR ? ld_rec_u(rec, e0 + i + 1) : ld_rec(rec, e0 + i + 1);           // bracket [i+1, i+2]
     double const kc = cvt_keep(ON_EPS ? c.e1 : c.u1);
@@ -1113,6 +1114,9 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
     if constexpr (REC) {   // one record per bracket: keys and both slopes in one fetch
       Rec r[2];
       ld_rec2(D.recb, e0[0] + i[0], e0[1] + i[1], r[0], r[1]);      // both fetches in flight, then one curve after the other
+      // (carrying the four table values of a record as doubles, converted where the record is fetched, costs four more
+      // registers than the floats with the two keys the searches hold: 65 VGPRs, the eighth wavefront gone, 36.5 against
+      // 35.0 ms -- with the shorter chain of fetches the eighth wavefront matters again)
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         double ka, kb;
