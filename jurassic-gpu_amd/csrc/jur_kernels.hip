@@ -1099,6 +1099,8 @@ __device__ __forceinline__ double ega_eps_warm(jur_view_t const &v, jur_int2 con
   if (RCPB && (tau != tau || t != t || u != u || p != p)) return __builtin_nan("");
   double const eps = 1 - tau;
   double eps_p0 = 0, eps_p1 = 0;
+  // (the records of BOTH levels requested before any is used: 92 VGPRs -- 40.9 ms at 5 wavefronts per SIMD, 101 ms with the
+  // excess in scratch at 6, against 35.0: profiles/r04_ega_bracket_records_experiment.json)
 #pragma unroll 1
   for (int h = 0; h < 2; h++) {  // pressure level l0, then l1
     unsigned const kc = h ? k1 + (unsigned)it1 : k0 + (unsigned)it0;
@@ -1630,7 +1632,7 @@ __global__ __launch_bounds__(1024, WAVES) void jur_ega_group_kernel(jur_view_t v
           if (nan_in || tau != tau) tau_new = __builtin_nan("");
           else {
             long long const pe0 = ld_scalar<long long>(v.ega_items, item_byte + (unsigned)offsetof(jur_item_t, e0) + ku * 8u);
-            void const *const ueb = v.ue + pe0, *const slb = v.sl + pe0;
+            void const *const recb = v.rec + pe0;
             double const eps = 1 - tau;
             double eps_p0 = 0, eps_p1 = 0;
 #pragma unroll 1
@@ -1641,25 +1643,23 @@ __global__ __launch_bounds__(1024, WAVES) void jur_ega_group_kernel(jur_view_t v
               unsigned const e0[2] = {(unsigned)ea, (unsigned)eb};
               int const n[2] = {eb - ea, ec_ - eb};
               int i[2] = {(int)(packed & 0xffffu), (int)(packed >> 16)};
-              Ue a[2], bb[2];
 #pragma unroll
               for (int q = 0; q < 2; q++) i[q] = min(i[q], n[q] - 2);
-              ld_pair2(ueb, e0[0] + i[0], e0[1] + i[1], a[0], bb[0], a[1], bb[1]);
-              double x[2], ec[2], ka[2], kb[2], s[2];
+              double x[2], ec[2];
+              {   // bracket records (one fetch per curve), as jur_ega_kernel
+                Rec r[2];
+                ld_rec2(recb, e0[0] + i[0], e0[1] + i[1], r[0], r[1]);
 #pragma unroll
-              for (int q = 0; q < 2; q++) seek_curve_keys<true, false>(ueb, e0[q], n[q], eps, i[q], a[q], bb[q], ka[q], kb[q]);
-              ld_slope2<0>(slb, e0[0] + i[0], e0[1] + i[1], s[0], s[1]);
-#pragma unroll
-              for (int q = 0; q < 2; q++) {
-                double const ya = kkey<false>(a[q]), yb = kkey<false>(bb[q]);
-                x[q] = lip_slope(ka[q], ya, s[q], eps) + u;
-                ka[q] = ya; kb[q] = yb;
+                for (int q = 0; q < 2; q++) {
+                  double ka, kb;
+                  seek_rec<true, false>(recb, e0[q], n[q], eps, i[q], r[q], ka, kb);
+                  double const ya = cvt_keep(r[q].u0);
+                  x[q] = lip_slope(ka, ya, r[q].du_de, eps) + u;
+                  ka = ya; kb = cvt_keep(r[q].u1);
+                  seek_rec<false, true>(recb, e0[q], n[q], x[q], i[q], r[q], ka, kb);
+                  ec[q] = c01_num(lip_slope(ka, (double)r[q].e0, r[q].de_du, x[q]));
+                }
               }
-#pragma unroll
-              for (int q = 0; q < 2; q++) seek_curve_keys<false, true>(ueb, e0[q], n[q], x[q], i[q], a[q], bb[q], ka[q], kb[q]);
-              ld_slope2<1>(slb, e0[0] + i[0], e0[1] + i[1], s[0], s[1]);
-#pragma unroll
-              for (int q = 0; q < 2; q++) ec[q] = c01_num(lip_slope(ka[q], (double)a[q].eps, s[q], x[q]));
               pos[h ? HS : 0] = (unsigned)i[0] | ((unsigned)i[1] << 16);
               // lip_mulr(T0, ec0, ec1, t, rt) with its (t - T0) formed above
               double const e = c01_num(ec[0] + ((h ? dt1 : dt0) * (ec[1] - ec[0])) * sRT[kc]);
@@ -2519,7 +2519,7 @@ static int launch_ega_group(jur_view_t const *v, jur_chunk_t const *c, hipStream
   static int const env_group = getenv("JUR_EGA_GROUP") ? atoi(getenv("JUR_EGA_GROUP")) : -1;      // A/B switches, read once
   static int const env_block = getenv("JUR_EGA_BLOCK") ? atoi(getenv("JUR_EGA_BLOCK")) : 0;
   static int const env_waves = getenv("JUR_EGA_WAVES") ? atoi(getenv("JUR_EGA_WAVES")) : 0;
-  if (!v->ega_items || v->ega_nitems <= 0 || v->ega_nch < 2 || !v->fast_arith || env_group == 0 || getenv("JUR_EGA_NO_LDS")) return -1;
+  if (!v->ega_items || v->ega_nitems <= 0 || v->ega_nch < 2 || !v->fast_arith || !v->rec || env_group == 0 || getenv("JUR_EGA_NO_LDS")) return -1;
   int const block = (env_block >= 64 && env_block <= 1024 && env_block % 64 == 0) ? env_block : 256;
   int const waves = env_waves >= 6 && env_waves <= 8 ? env_waves : 7;
   size_t const lds = ega_group_lds_bytes(v->max_pair_curves, v->ega_nch, block);

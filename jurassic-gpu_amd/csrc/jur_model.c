@@ -309,7 +309,7 @@ int jur_model_set_ega_group(jur_model_t *m, int nch) {
 }
 
 /* channels per lane the next call's look-up kernel walks (0: one pair per workgroup) */
-int jur_model_ega_group(jur_model_t const *m) { return (m->view.ega_items && m->view.fast_arith) ? m->view.ega_nch : 0; }
+int jur_model_ega_group(jur_model_t const *m) { return (m->view.ega_items && m->view.fast_arith && m->view.rec) ? m->view.ega_nch : 0; }
 
 int jur_model_create_from_files(jur_model_t **out, ctl_t const *ctl, int device) {
   *out = NULL;
