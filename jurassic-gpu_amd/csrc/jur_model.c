@@ -217,6 +217,10 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
       rc = JUR_EHIP;
     }
     v->rec = (jur_rec_t const *)m->d_rec;
+    if (!rc) {   /* every kernel of the strict-table arithmetic reads the records; the slope array was their source only */
+      (void)hipFree(m->d_sl);
+      m->d_sl = NULL;
+    }
   }
   if (!rc && fl.strict && npair > 0) {   /* which channels of a gas stand on one (p, T) grid: jur_model_set_ega_group */
     m->grid_cls = (int *)malloc(sizeof(int) * npair);
@@ -231,7 +235,7 @@ int jur_model_create(jur_model_t **out, ctl_t const *ctl, jur_tables_t const *tb
   v->sorted_tables = fl.sorted;
   v->strict_tables = fl.strict;
   v->max_pair_curves = fl.max_pair_curves;
-  m->table_bytes = (long)((sizeof(jur_ue_t) + (fl.strict ? sizeof(jur_sl_t) : 0) + (m->d_rec ? sizeof(jur_rec_t) : 0)) * fl.nentry + 16 * fl.ncurve + 16 * fl.nlevel + 8 * npair);
+  m->table_bytes = (long)((sizeof(jur_ue_t) + (m->d_sl ? sizeof(jur_sl_t) : 0) + (m->d_rec ? sizeof(jur_rec_t) : 0)) * fl.nentry + 16 * fl.ncurve + 16 * fl.nlevel + 8 * npair);
   jur_flat_free(&fl);
   if (rc) { jur_model_destroy(m); return rc; }
   v->chan = (jur_chan_t const *)m->d_chan;
@@ -281,7 +285,7 @@ int jur_model_set_arithmetic(jur_model_t *m, int mode) {
   /* (the staging size of jurk_launch_ega: 24 B per level and curve of the largest pair, at most 48 KB) */
   int const lds_ok = v->max_pair_curves > 0 && 24L * JUR_TBLNP + 24L * v->max_pair_curves <= 48 * 1024 && !getenv("JUR_EGA_NO_LDS");
   m->arith = mode;
-  v->fast_arith = (mode == JUR_ARITH_FAST) && v->strict_tables && v->sl && lds_ok;
+  v->fast_arith = (mode == JUR_ARITH_FAST) && v->strict_tables && (v->sl || v->rec) && lds_ok;
   return JUR_OK;
 }
 int jur_model_arithmetic(jur_model_t const *m) { return m->arith; }
