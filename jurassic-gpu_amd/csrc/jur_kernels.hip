@@ -311,7 +311,7 @@ __device__ __forceinline__ double quad_bcast(double x) {
 // One line of sight (traceray, jr_common.h:585-711, with tangent_point :502-539, trapezoid_rule_pos :437-443 and
 // column_density :446-453 folded in), one lane per ray.  L says where the LOS fields of a point live -- the HBM
 // workspace of the batched kernels, or a ring in LDS in the fused kernel -- through
-//   L.at(field, point)      reference to the field's slot
+//   L.at(field, point)      reference to the field's slot;  L.put(field, point, x) writes it
 //   L.field_stride()        distance between the slots of consecutive fields (the emitters' columns are consecutive)
 //   L.begin_point(i)        called before point i is first written
 //   L.points_final(i)       called when points 0 .. i-1 will not change any more (point i still may: the exit
@@ -442,7 +442,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
           if (low_idx == np - 1) TR_LDS1 = dsp;
           if (low_idx + 1 == np - 1) TR_LDS2 = dsp;
           double const dsn = (np >= 2) ? 0.5 * (ds_pp + dsp) : dsp * 0.5;
-          L.at(JUR_F_DS, np - 1) = dsn;
+          L.put(JUR_F_DS, np - 1, dsn);
           redo_columns(v.atm_z, v.atm_q, v.atm_np, atm0, atmn, v.ng, TR_PZ, L.at(JUR_F_P, np - 1), L.at(JUR_F_T, np - 1), dsn,
                        &L.at(f_u, np - 1), L.field_stride());
           ds_p = dsp;
@@ -453,7 +453,7 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
       double p, t, rdz = 0;
       int const ia = intpol_pt<true>(v, atm0, atmn, z, p, t, zdir, zhint, &rdz);
       double const dsn = (np >= 1) ? 0.5 * (ds_p + ds) : ds * 0.5;   // redone for the point before the exit
-      L.at(JUR_F_DS, np) = dsn;
+      L.put(JUR_F_DS, np, dsn);
       {  // remaining quantities on the same bracket (jr_common.h:557-567)
         double const za = v.atm_z[ia], zb = v.atm_z[ia + 1];
         double const kt = JUR_BOLTZMANN * t, rkt = 1. / kt;   // one division for all emitters' columns (div_rcp)
@@ -462,17 +462,17 @@ __device__ __forceinline__ TraceResult trace_ray(jur_view_t const &v, double con
           double const *q = v.atm_q + (size_t)ig * v.atm_np;
           double qv;
           if (zdir) qv = lip_rcp(za, q[ia], zb, q[ia + 1], z, rdz); else qv = lip(za, q[ia], zb, q[ia + 1], z);
-          L.at(f_u + ig, np) = div_rcp(10. * qv * p, kt, rkt) * dsn;
-          if (ig == v.ig_h2o) L.at(JUR_F_QH2O, np) = qv;
+          L.put(f_u + ig, np, div_rcp(10. * qv * p, kt, rkt) * dsn);
+          if (ig == v.ig_h2o) L.put(JUR_F_QH2O, np, qv);
         }
         for (int iw = 0; iw < v.nw; iw++) {
           double const *k = v.atm_k + (size_t)iw * v.atm_np;
-          if (zdir) L.at(f_k + iw, np) = lip_rcp(za, k[ia], zb, k[ia + 1], z, rdz);
-          else L.at(f_k + iw, np) = lip(za, k[ia], zb, k[ia + 1], z);
+          if (zdir) L.put(f_k + iw, np, lip_rcp(za, k[ia], zb, k[ia + 1], z, rdz));
+          else L.put(f_k + iw, np, lip(za, k[ia], zb, k[ia + 1], z));
         }
       }
-      L.at(JUR_F_P, np) = p;
-      L.at(JUR_F_T, np) = t;
+      L.put(JUR_F_P, np, p);
+      L.put(JUR_F_T, np, t);
       ds_pp = ds_p; ds_p = ds;
 
       if (low_idx >= 0 && low_idx == np - 1) { TR_LZ2 = z; TR_LDS2 = ds; for (int i = 0; i < 3; i++) TR_LX2(i) = x[i]; }
@@ -606,6 +606,11 @@ struct LosWorkspace {
   double *tile;                 // first double of this wavefront's tile, + lane
   int nfield;
   __device__ __forceinline__ double &at(int field, int ip) const { return tile[((size_t)ip * nfield + field) * 64]; }
+  // the LOS rows leave the tracer for good (the look-up kernel reads them from HBM, 20 GB per 1e6 limb rays later):
+  // written past the L2, which then keeps the atmosphere's profiles -- jur_trace_kernel 8.23 -> 7.70 ms per 1e6 limb rays
+  __device__ __forceinline__ void put(int field, int ip, double x) const {
+    __builtin_nontemporal_store(x, &tile[((size_t)ip * nfield + field) * 64]);
+  }
   __device__ __forceinline__ size_t field_stride() const { return 64; }
   __device__ __forceinline__ void begin_point(int) const {}
   __device__ __forceinline__ void points_final(int) const {}
@@ -683,6 +688,17 @@ static_assert(sizeof(Lvl) == sizeof(jur_lvl_t) && sizeof(Crv) == sizeof(jur_crv_
 template <class T>
 __device__ __forceinline__ T ldg(void const *__restrict__ base, unsigned index) {
   return *reinterpret_cast<T const *>(static_cast<char const *>(base) + (size_t)(index * (unsigned)sizeof(T)));
+}
+// The path transmittances -- 40 GB per 1e6 limb rays, written once by the look-up kernel and read once by the radiance
+// update -- go past the L2 as non-temporal accesses: the lines that ARE re-used there (the LOS rows the workgroups of a
+// ray block share, the tables) stay longer.  Measured (round 4, profiles/r04_cache_policy_experiment.json): look-up
+// 35.1 -> 33.7 ms with the stores, radiance update 10.69 -> 10.53 ms with the loads.  The LOS loads of the look-up as
+// non-temporal: 38.5 ms -- that re-use is real.
+__device__ __forceinline__ void st_stream(double *base, unsigned lane, double x) {
+  __builtin_nontemporal_store(x, reinterpret_cast<double *>(reinterpret_cast<char *>(base) + (size_t)(lane * 8u)));
+}
+__device__ __forceinline__ double ld_stream(double const *__restrict__ base, unsigned lane) {
+  return __builtin_nontemporal_load(reinterpret_cast<double const *>(reinterpret_cast<char const *>(base) + (size_t)(lane * 8u)));
 }
 __device__ __forceinline__ Ue ld_ue(void const *__restrict__ ue, unsigned idx) { return ldg<Ue>(ue, idx); }
 // entries idx and idx+1 of a curve are adjacent: one 16-byte load
@@ -1502,7 +1518,7 @@ __global__ __launch_bounds__(256, REC ? JUR_REC_WAVES : 5) void jur_ega_kernel(j
     if constexpr (RCPB) tau_path = ega_eps_warm<LDS, true, true, REC>(v, pd, D, tau_path, t, u, p, br, ia, ib);
     else if constexpr (WARM) tau_path *= ega_eps_warm<LDS, false>(v, pd, D, tau_path, t, u, p, br, ia, ib);
     else tau_path *= ega_eps_exact<LDS>(v, pd, D, tau_path, t, u, p);
-    *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)(lane * 8u)) = tau_path;
+    st_stream(out + (size_t)ip * Re, lane, tau_path);
   }
 }
 
@@ -1672,7 +1688,7 @@ __global__ __launch_bounds__(1024, WAVES) void jur_ega_group_kernel(jur_view_t v
       mytau[k * BLOCK] = tau_new;
       int const dk = ld_scalar<int>(v.ega_items, item_byte + (unsigned)offsetof(jur_item_t, d) + ku * 4u);
       double *const out = out_tile + (size_t)(dk * v.ng + g) * 64;
-      *reinterpret_cast<double *>(reinterpret_cast<char *>(out + (size_t)ip * Re) + (size_t)(lane * 8u)) = tau_new;
+      st_stream(out + (size_t)ip * Re, lane, tau_new);
     }
   }
 }
@@ -1696,13 +1712,13 @@ __device__ __forceinline__ SegmentIn load_segment(double const *__restrict__ row
   in.u_h2o = ldg<double>(row + (size_t)f_h2o * 64, lane);
   double tg[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) tg[k] = (k < ng && ((has_table >> k) & 1u)) ? ldg<double>(trow + (size_t)k * 64, lane) : 1.0;
+  for (int k = 0; k < 8; k++) tg[k] = (k < ng && ((has_table >> k) & 1u)) ? ld_stream(trow + (size_t)k * 64, lane) : 1.0;
   double pcur = 1.0;
 #pragma unroll
   for (int k = 0; k < 8; k++) pcur *= tg[k];           // (x * 1.0 == x: absent gases do not change the product)
   for (int g0 = 8; g0 < ng; g0 += 8) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) tg[k] = (g0 + k < ng && g0 + k < 32 && ((has_table >> (g0 + k)) & 1u)) ? ldg<double>(trow + (size_t)(g0 + k) * 64, lane) : 1.0;
+    for (int k = 0; k < 8; k++) tg[k] = (g0 + k < ng && g0 + k < 32 && ((has_table >> (g0 + k)) & 1u)) ? ld_stream(trow + (size_t)(g0 + k) * 64, lane) : 1.0;
 #pragma unroll
     for (int k = 0; k < 8; k++) pcur *= tg[k];
   }
@@ -1912,6 +1928,7 @@ struct LosRing {
   int nfield, RB, r, nc;
   int shift;               // lanes per ray in the tracer wavefront = 1 << shift (ray slot = lane >> shift)
   __device__ __forceinline__ double &at(int field, int ip) const { return ring[((ip & (PEN_RING - 1)) * nfield + field) * RB + r]; }
+  __device__ __forceinline__ void put(int field, int ip, double x) const { at(field, ip) = x; }
   __device__ __forceinline__ size_t field_stride() const { return (size_t)RB; }
   __device__ __forceinline__ void begin_point(int ip) const {   // the slot still holds point ip - PEN_RING
     if (ip >= PEN_RING)
@@ -2544,7 +2561,7 @@ extern "C" int jurk_launch_ega(jur_view_t const *v, jur_chunk_t const *c, void *
     int const e = launch_ega_group(v, c, (hipStream_t)stream);
     if (e >= 0) return e;
   }
-  int const block = 256;
+  int const block = 256;   // (128 rays per workgroup: 34.6 against 33.7 ms; 64: the staged descriptors limit the occupancy, 45 ms)
   int const nrb = (c->n + block - 1) / block, npair = v->nd * v->ng;
   unsigned const grid = xcd_grid(nrb, npair);
   hipStream_t s = (hipStream_t)stream;
