@@ -334,6 +334,19 @@ def test_kernel_register_budgets(tmp_path):
         (vgprs, scratch), = hits.values()
         assert vgprs <= limit and scratch <= scratch_limit, (key, vgprs, scratch)
 
+    # the cache policy of the three streams that are written once and read once (profiles/
+    # r04_cache_policy_experiment.json): non-temporal stores of the path transmittances and of the tracer's LOS rows,
+    # non-temporal loads of the transmittances in the radiance update -- and NOT of the look-up's LOS rows
+    def body(key):
+        (name,) = [n for n in seen if key in n and "kat" not in n]
+        start = text.index("\n" + name + ":")
+        return text[start:text.index("s_endpgm", start)]
+    nt = lambda code, op: len(re.findall(r"^\s*%s\S*\s.*\bnt\b" % op, code, re.M))
+    ega = body("jur_ega_kernelILb1ELb1ELb1ELb1E")
+    assert nt(ega, "global_store") >= 1 and nt(ega, "global_load") == 0, (nt(ega, "global_store"), nt(ega, "global_load"))
+    assert nt(body("jur_trace_kernel"), "global_store") >= 5      # (the emitter and window loops are rolled in this build)
+    assert nt(body("jur_combine_group_kernel"), "global_load") >= 1 and nt(body("jur_combine_kernel"), "global_load") >= 1
+
 
 def test_los_point_estimate_balances_a_sorted_scan(oracle):
     """jur_estimate_los_points / jur_balance_rays (host arithmetic of the library, no GPU): the closed-form estimate of the
